@@ -1,0 +1,109 @@
+// common.h — types, the fragment-tiled split-bf16 layout, and small device helpers.
+//
+// Data layout used for every intermediate tensor and every weight (gfx950-first design):
+//
+//   * split-bf16: an fp32 value v is stored as two bf16 numbers hi = rn(v), lo = rn(v - hi)
+//     in two separate planes.  A contraction then runs as three bf16 MFMAs
+//     (hi*hi + lo*hi + hi*lo, fp32 accumulate), which keeps ~16 mantissa bits per operand —
+//     the reference's fp32 results are reproduced to ~1e-5 where plain bf16 gives ~1e-2
+//     (SURVEY.md §7 "hard parts").  The split is done ONCE, in the epilogue of the kernel that
+//     produces the value, never in a consumer's main loop.
+//
+//   * fragment-tiled: a [R][K] matrix (R % 32 == 0, K % 16 == 0) is stored as
+//     [R/32][K/16][2][32][8] bf16, i.e. one contiguous 1 KiB block per (32 rows x 16 k) MFMA
+//     operand fragment, ordered exactly as v_mfma_f32_32x32x16_bf16 wants it: lane l of a wave
+//     reads its 8 bf16 (16 bytes) at block_base + 16*l.  Global->LDS staging is therefore a
+//     straight copy of contiguous kilobytes, LDS fragment reads are lane-linear 16-byte reads
+//     (bank-conflict free by construction, no padding, no swizzle), and epilogues write 8 or 16
+//     contiguous bytes per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define EG_HD __host__ __device__ __forceinline__
+#define EG_D __device__ __forceinline__
+
+// Element index of (row r, column k) inside one fragment-tiled plane with K/16 == K16.
+EG_HD size_t tiled_index(int r, int k, int K16) {
+    return ((((size_t)(r >> 5) * (size_t)K16 + (size_t)(k >> 4)) * 2 + (size_t)((k >> 3) & 1)) << 8) +
+           (size_t)((r & 31) << 3) + (size_t)(k & 7);
+}
+
+EG_D void split_bf16(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+// Split four fp32 values and pack them as 2 x (4 bf16 = 8 bytes).
+EG_D void split4(const float v[4], uint2& hi, uint2& lo) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __bf16 a, b;
+        split_bf16(v[i], a, b);
+        h[i] = a;
+        l[i] = b;
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+EG_D void unpack4(uint2 hi, uint2 lo, float v[4]) {
+    bf16x4 h = __builtin_bit_cast(bf16x4, hi);
+    bf16x4 l = __builtin_bit_cast(bf16x4, lo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)h[i] + (float)l[i];
+}
+
+EG_D void unpack4_hi(uint2 hi, float v[4]) {
+    bf16x4 h = __builtin_bit_cast(bf16x4, hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)h[i];
+}
+
+EG_D int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// Row of accumulator register r of v_mfma_f32_32x32x16_bf16 for a lane in half hf (= lane >> 5):
+// row = (r & 3) + 8 * (r >> 2) + 4 * hf; the column is lane & 31.
+EG_D int mfma32_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+// --------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator + Box-Muller: four N(0,1) per call.
+struct Philox4 {
+    uint32_t c[4];
+};
+
+EG_D Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 r;
+    r.c[0] = c0; r.c[1] = c1; r.c[2] = c2; r.c[3] = c3;
+    return r;
+}
+
+EG_D void philox_normal4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float out[4]) {
+    Philox4 r = philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // (0,1] uniforms from 32 random bits, then Box-Muller on two pairs.
+    const float inv = 2.3283064365386963e-10f;  // 2^-32
+    float u0 = ((float)r.c[0] + 1.0f) * inv, u1 = (float)r.c[1] * inv;
+    float u2 = ((float)r.c[2] + 1.0f) * inv, u3 = (float)r.c[3] * inv;
+    u0 = fminf(u0, 1.0f);
+    u2 = fminf(u2, 1.0f);
+    float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float s0, c0f, s1, c1f;
+    sincosf(6.283185307179586f * u1, &s0, &c0f);
+    sincosf(6.283185307179586f * u3, &s1, &c1f);
+    out[0] = ra * c0f; out[1] = ra * s0; out[2] = rb * c1f; out[3] = rb * s1;
+}

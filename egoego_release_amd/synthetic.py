@@ -1,0 +1,115 @@
+"""Deterministic synthetic weights and head-pose windows.
+
+The reference ships no pretrained weights, datasets or tests, so
+parity fixtures, the GPU parity tests and bench.py all use seeded random
+weights in the reference's checkpoint layout
+(/root/reference/egoego/model/transformer_cond_diffusion_model.py:143-214 and
+egoego/model/transformer_module.py:36-186 define the tensors and their init
+scales).  Values come from numpy's PCG64 keyed by (seed, tensor name), so the
+same state dict can be rebuilt anywhere without shipping 44 MB of weights.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+class ModelConfig:
+    """Shapes of the stage-2 denoiser as run_egoego.py / eval_stage2.py build it
+    (/root/reference/trainer_amass_cond_motion_diffusion.py:458-475)."""
+
+    def __init__(self, d_feats=198, d_model=512, n_head=4, n_dec_layers=4, d_k=256, d_v=256,
+                 max_timesteps=121, timesteps=1000, objective="pred_x0"):
+        self.d_feats, self.d_model, self.n_head = d_feats, d_model, n_head
+        self.n_dec_layers, self.d_k, self.d_v = n_dec_layers, d_k, d_v
+        self.max_timesteps, self.timesteps, self.objective = max_timesteps, timesteps, objective
+
+    def ctor_kwargs(self):
+        return dict(d_feats=self.d_feats, d_model=self.d_model, n_head=self.n_head,
+                    n_dec_layers=self.n_dec_layers, d_k=self.d_k, d_v=self.d_v,
+                    max_timesteps=self.max_timesteps, out_dim=self.d_feats,
+                    timesteps=self.timesteps, objective=self.objective)
+
+
+def _rng(seed, name):
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def _normal(seed, name, shape, std):
+    return torch.from_numpy((_rng(seed, name).standard_normal(shape) * std).astype(np.float32))
+
+
+def _uniform(seed, name, shape, bound):
+    return torch.from_numpy(_rng(seed, name).uniform(-bound, bound, shape).astype(np.float32))
+
+
+def sinusoid_position_table(n_position, d_hid):
+    """Frozen table of transformer_module.py:6-24 (float64 math, row 0 zeroed)."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    ang = pos / np.power(10000, 2 * (j // 2) / d_hid)
+    tab = np.where(j % 2 == 0, np.sin(ang), np.cos(ang))
+    tab[0] = 0.0
+    return torch.from_numpy(tab.astype(np.float32))
+
+
+def make_weights(cfg, seed=0):
+    """Learnable tensors + the frozen position table, keyed like the reference state dict
+    (without the 13 schedule buffers, which the module computes itself)."""
+    D, dm, H = cfg.d_feats, cfg.d_model, cfg.n_head
+    sd = {}
+    tr = "denoise_fn.motion_transformer."
+
+    def lin(name, out_f, in_f, conv=False):
+        b = 1.0 / np.sqrt(in_f)  # PyTorch default kaiming_uniform(a=sqrt(5)) bound
+        shape = (out_f, in_f, 1) if conv else (out_f, in_f)
+        sd[name + ".weight"] = _uniform(seed, name + ".weight", shape, b)
+        sd[name + ".bias"] = _uniform(seed, name + ".bias", (out_f,), b)
+
+    lin(tr + "start_conv", dm, 2 * D, conv=True)
+    sd[tr + "position_vec.weight"] = sinusoid_position_table(cfg.max_timesteps + 1, dm)
+    for i in range(cfg.n_dec_layers):
+        a = tr + f"layer_stack.{i}.self_attn."
+        for nm, dd in (("w_q", cfg.d_k), ("w_k", cfg.d_k), ("w_v", cfg.d_v)):
+            sd[a + nm + ".weight"] = _normal(seed, a + nm + ".weight", (H * dd, dm), np.sqrt(2.0 / (dm + dd)))
+            sd[a + nm + ".bias"] = _uniform(seed, a + nm + ".bias", (H * dd,), 1.0 / np.sqrt(dm))
+        sd[a + "fc.weight"] = _normal(seed, a + "fc.weight", (dm, H * cfg.d_v), np.sqrt(2.0 / (dm + H * cfg.d_v)))
+        sd[a + "fc.bias"] = _uniform(seed, a + "fc.bias", (dm,), 1.0 / np.sqrt(H * cfg.d_v))
+        f = tr + f"layer_stack.{i}.pos_ffn."
+        lin(f + "w_1", dm, dm, conv=True)
+        lin(f + "w_2", dm, dm, conv=True)
+        for ln in (a + "layer_norm", f + "layer_norm"):
+            # perturbed affine so a gamma/beta mix-up cannot hide behind the 1/0 default init
+            sd[ln + ".weight"] = 1.0 + _normal(seed, ln + ".weight", (dm,), 0.1)
+            sd[ln + ".bias"] = _normal(seed, ln + ".bias", (dm,), 0.1)
+    lin("denoise_fn.linear_out", D, dm)
+    lin("denoise_fn.time_mlp.1", 256, 64)
+    lin("denoise_fn.time_mlp.3", dm, 256)
+    return sd
+
+
+def head_condition_mask(shape, device="cpu"):
+    """1 on dims the model must synthesise, 0 on the head joint's position (45:48) and 6D
+    rotation (156:162) — trainer_amass_cond_motion_diffusion.py:210-221."""
+    m = torch.ones(shape, device=device)
+    m[..., 45:48] = 0
+    m[..., 156:162] = 0
+    return m
+
+
+def make_head_windows(B, T, seed=0, d_feats=198):
+    """Synthetic normalised head-pose windows: zeros except a clipped random
+    walk on the head position dims and the first two rows of random rotations on the head
+    rot6d dims.  Returns (x_start [B,T,D], cond_mask [B,T,D])."""
+    g = np.random.Generator(np.random.PCG64([seed, 7]))
+    x = np.zeros((B, T, d_feats), dtype=np.float32)
+    walk = np.cumsum(g.standard_normal((B, T, 3)) * 0.02, axis=1) + g.uniform(-0.5, 0.5, (B, 1, 3))
+    x[..., 45:48] = np.clip(walk, -1, 1)
+    q = g.standard_normal((B, T, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, a, b, c = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    r0 = np.stack([1 - 2 * (b * b + c * c), 2 * (a * b - c * w), 2 * (a * c + b * w)], -1)
+    r1 = np.stack([2 * (a * b + c * w), 1 - 2 * (a * a + c * c), 2 * (b * c - a * w)], -1)
+    x[..., 156:159], x[..., 159:162] = r0, r1
+    xs = torch.from_numpy(x)
+    return xs, head_condition_mask(xs.shape)
