@@ -1,0 +1,208 @@
+// attention.h — full (unmasked) multi-head self-attention over one window, split-bf16 MFMA.
+//
+// Replaces TM:75-88 (bmm, /temperature, softmax, bmm, head merge) for use_full_attention=True.
+// One workgroup (4 waves) per (batch, head, group of 4 query tiles); wave w owns 32 queries.
+//
+//   S^T[key][query] = K_frag (A, rows = keys) x Q_frag (B, cols = queries)   ("swapped" QK^T)
+// puts a whole softmax row in ONE lane pair (lane, lane^32): the row max / sum are in-lane
+// reductions plus one cross-half shuffle, and the probabilities never leave registers: the
+// S^T accumulator registers 8jj..8jj+7 of key tile kt ARE the B-operand fragment of
+//   O^T[d][query]  = V^T_frag (A, rows = d) x P_frag (B, cols = queries)
+// for key group kg = 2*kt + jj, because the V projection's epilogue (gemm.h EpiV) already stored V
+// transposed with the keys of each group of 16 in exactly that (half, slot) order.
+// The attention matrix itself is never written (the reference returns and discards it, TM:95,223).
+//
+// K (4 chunks of 64 of d_k) and then V^T (4 chunks of 64 of d_v) stream through a double-buffered
+// LDS ring as contiguous kilobyte fragments; Q fragments go global -> registers (each is used by one
+// wave only).  8 phases, one barrier each; the next phase's loads are in flight during the MFMAs.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+struct AttnArgs {
+    const __bf16* q;  // [B][H][L/32][16][2][32][8], pre-scaled by 1/temperature
+    const __bf16* k;  // same layout
+    const __bf16* v;  // [B][H][8][L/16][2][32][8], transposed + key-permuted
+    size_t plane;     // elements between hi and lo planes of q/k/v
+    __bf16* o;        // fragment-tiled [Mp][HD]
+    size_t o_plane;
+    int HD16;  // H*256/16
+    int H;
+    int L;     // valid keys (T + 1); keys >= L are padding and get probability 0
+};
+
+template <int KT, int NP>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCH = KT * NP;                  // 16-byte chunks per thread per phase
+    constexpr int STAGE_BYTES = KT * NP * 4096;   // K chunk: KT tiles x NP planes x 4 k-steps x 1 KiB
+    constexpr int Lp = KT * 32;
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63;
+    const int hf = lane >> 5, col = lane & 31;
+    const int bh = blockIdx.y;
+    const int qt_raw = blockIdx.x * 4 + wave;
+    const bool active = qt_raw < KT;
+    const int qt = active ? qt_raw : KT - 1;
+
+    auto stage_src = [&](int ph, int j) -> const u32x4* {
+        const int blk = j * 4 + wave;
+        if (ph < 4) {
+            const int ks = blk & 3, t2 = blk >> 2;
+            const int p = t2 / KT, kt = t2 % KT;
+            return (const u32x4*)(a.k + (size_t)p * a.plane) + (((size_t)bh * KT + kt) * 16 + 4 * ph + ks) * 64 + lane;
+        } else {
+            const int kg = blk % (2 * KT), t2 = blk / (2 * KT);
+            const int p = t2 >> 1, dt2 = t2 & 1;
+            return (const u32x4*)(a.v + (size_t)p * a.plane) +
+                   (((size_t)bh * 8 + 2 * (ph - 4) + dt2) * (2 * KT) + kg) * 64 + lane;
+        }
+    };
+    auto q_src = [&](int dc, int ks, int p) -> const u32x4* {
+        return (const u32x4*)(a.q + (size_t)p * a.plane) + (((size_t)bh * KT + qt) * 16 + 4 * dc + ks) * 64 + lane;
+    };
+
+    f32x16 s[KT];
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
+    bf16x8 phi[KT][2], plo[KT][2];
+
+    u32x4 qb[2][4][NP];  // Q fragments of the current / next d_k chunk (static ping-pong)
+    {
+        u32x4 st[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) st[j] = *stage_src(0, j);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) qb[0][ks][p] = *q_src(0, ks, p);
+        char* dst = smem + ((size_t)wave * 64 + lane) * 16;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * 4096) = st[j];
+    }
+    __syncthreads();
+
+    auto phase = [&](auto PHC) {
+        constexpr int ph = decltype(PHC)::value;
+        constexpr int buf = ph & 1;
+        u32x4 st[NCH];
+        if constexpr (ph < 7) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) st[j] = *stage_src(ph + 1, j);
+        }
+        if constexpr (ph < 3) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) qb[(ph + 1) & 1][ks][p] = *q_src(ph + 1, ks, p);
+        }
+        const char* sb = smem + (size_t)buf * STAGE_BYTES + lane * 16;
+        if constexpr (ph < 4) {
+            // S^T += K_chunk x Q_chunk^T
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 qh = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][0]);
+                const bf16x8 ql = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][NP - 1]);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const bf16x8 kh = *(const bf16x8*)(sb + ((0 * KT + kt) * 4 + ks) * 1024);
+                    if constexpr (NP == 2) {
+                        const bf16x8 kl = *(const bf16x8*)(sb + ((1 * KT + kt) * 4 + ks) * 1024);
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, s[kt], 0, 0, 0);
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, s[kt], 0, 0, 0);
+                    }
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, s[kt], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (ph == 3) {
+            // softmax over keys (TM:82); lane (col, hf) holds keys 32kt + 8(r>>2) + 4hf + (r&3)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * kt + mfma32_row(r, hf);
+                    if (key >= a.L) s[kt][r] = -INFINITY;
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[kt][r] = expf(s[kt][r] - mx);
+                    sum += s[kt][r];
+                }
+            sum += __shfl_xor(sum, 32);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        __bf16 x, y;
+                        split_bf16(s[kt][8 * jj + e] / sum, x, y);
+                        phi[kt][jj][e] = x;
+                        plo[kt][jj][e] = y;
+                    }
+        }
+        if constexpr (ph >= 4) {
+            // O^T[64 of d_v][32 queries] = V^T_chunk x P
+            f32x16 o[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < 2 * KT; ++kg) {
+                const bf16x8 ph_ = phi[kg >> 1][kg & 1];
+                const bf16x8 pl_ = plo[kg >> 1][kg & 1];
+#pragma unroll
+                for (int dt2 = 0; dt2 < 2; ++dt2) {
+                    const bf16x8 vh = *(const bf16x8*)(sb + ((0 * 2 + dt2) * (2 * KT) + kg) * 1024);
+                    if constexpr (NP == 2) {
+                        const bf16x8 vl = *(const bf16x8*)(sb + ((1 * 2 + dt2) * (2 * KT) + kg) * 1024);
+                        o[dt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph_, o[dt2], 0, 0, 0);
+                        o[dt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl_, o[dt2], 0, 0, 0);
+                    }
+                    o[dt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph_, o[dt2], 0, 0, 0);
+                }
+            }
+            if (active) {
+                const int b = bh / a.H, h = bh % a.H;
+                const int m = b * Lp + qt * 32 + col;
+#pragma unroll
+                for (int dt2 = 0; dt2 < 2; ++dt2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int f = h * 256 + (2 * (ph - 4) + dt2) * 32 + 8 * g + 4 * hf;
+                        float v[4] = {o[dt2][4 * g + 0], o[dt2][4 * g + 1], o[dt2][4 * g + 2], o[dt2][4 * g + 3]};
+                        uint2 hi, lo;
+                        split4(v, hi, lo);
+                        const size_t idx = tiled_index(m, f, a.HD16);
+                        *(uint2*)(a.o + idx) = hi;
+                        if constexpr (NP == 2) *(uint2*)(a.o + a.o_plane + idx) = lo;
+                    }
+            }
+        }
+        if constexpr (ph < 7) {
+            char* dst = smem + (size_t)(buf ^ 1) * STAGE_BYTES + ((size_t)wave * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * 4096) = st[j];
+        }
+        __syncthreads();
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    phase(std::integral_constant<int, 4>{});
+    phase(std::integral_constant<int, 5>{});
+    phase(std::integral_constant<int, 6>{});
+    phase(std::integral_constant<int, 7>{});
+}

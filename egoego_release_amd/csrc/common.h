@@ -24,6 +24,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // one 16-byte chunk (native vector: stays in VGPRs)
 
 #define EG_HD __host__ __device__ __forceinline__
 #define EG_D __device__ __forceinline__
@@ -101,9 +102,11 @@ EG_D void philox_normal4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, u
     float u2 = ((float)r.c[2] + 1.0f) * inv, u3 = (float)r.c[3] * inv;
     u0 = fminf(u0, 1.0f);
     u2 = fminf(u2, 1.0f);
-    float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-    float s0, c0f, s1, c1f;
-    sincosf(6.283185307179586f * u1, &s0, &c0f);
-    sincosf(6.283185307179586f * u3, &s1, &c1f);
+    // v_log_f32 / v_sin_f32 / v_cos_f32 directly (the latter two take their argument in turns):
+    // statistical quality only matters here, and the libm versions drag scratch memory in.
+    const float ln2 = 0.6931471805599453f;
+    float ra = sqrtf(-2.0f * ln2 * __builtin_amdgcn_logf(u0)), rb = sqrtf(-2.0f * ln2 * __builtin_amdgcn_logf(u2));
+    const float s0 = __builtin_amdgcn_sinf(u1), c0f = __builtin_amdgcn_cosf(u1);
+    const float s1 = __builtin_amdgcn_sinf(u3), c1f = __builtin_amdgcn_cosf(u3);
     out[0] = ra * c0f; out[1] = ra * s0; out[2] = rb * c1f; out[3] = rb * s1;
 }

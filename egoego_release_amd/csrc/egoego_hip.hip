@@ -1,0 +1,696 @@
+// egoego_hip.hip — context, workspace carving, launch sequence and the C ABI (include/egoego_hip.h)
+// of the MI355X stage-2 diffusion sampling step.  gfx950 only.
+#include "../../include/egoego_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+#include "pointwise.h"
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(EGOEGO_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                         \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------ context
+struct LayerDev {
+    __bf16 *w_qkv, *w_fc, *w_1, *w_2;  // fragment-tiled, 2 planes each
+    float *b_qkv, *b_fc, *ln1_g, *ln1_b, *b_1, *b_2, *ln2_g, *ln2_b;
+};
+
+struct egoego_ctx {
+    egoego_config cfg;
+    int device;
+    int D, DP, KE, H, HD, NOUT, S;
+    std::vector<void*> allocs;
+    __bf16 *w_embed, *w_out;
+    float *b_embed, *b_out, *pe, *tt_table, *sched;
+    std::vector<LayerDev> layers;
+    bool have_weights, have_sched;
+    std::vector<float> abar_host;
+    // profiling
+    int prof_id;
+    std::vector<hipEvent_t> prof_events;
+};
+
+static const int N_MODEL = 512;
+
+struct Geometry {
+    int B, T, L, KT, Lp, Mp, Mvalid;
+};
+
+static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g) {
+    if (B < 1 || T < 1) return fail(EGOEGO_E_INVALID, "B and T must be positive (B=%d, T=%d)", B, T);
+    if (T > c->cfg.max_timesteps - 1)
+        return fail(EGOEGO_E_INVALID, "window length T=%d exceeds max_timesteps-1=%d (position table rows, TM:180-182)", T,
+                    c->cfg.max_timesteps - 1);
+    g.B = B; g.T = T; g.L = T + 1;
+    if (g.L <= 32) g.KT = 1;
+    else if (g.L <= 64) g.KT = 2;
+    else if (g.L <= 128) g.KT = 4;
+    else if (g.L <= 224) g.KT = 7;
+    else return fail(EGOEGO_E_INVALID, "window length T=%d not supported (T+1 must be <= 224)", T);
+    g.Lp = 32 * g.KT;
+    g.Mvalid = B * g.Lp;
+    g.Mp = (int)align_up((size_t)g.Mvalid, 128);
+    return 0;
+}
+
+struct Workspace {
+    int* t_idx;
+    float* row_mask;
+    __bf16 *xall, *hA, *hB, *F, *Q, *K, *V, *O;
+    size_t xall_plane, h_plane, qkv_plane, o_plane;
+    size_t total;
+};
+
+static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace& w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    w.t_idx = (int*)take(sizeof(int) * g.B);
+    w.row_mask = (float*)take(sizeof(float) * g.Mp);
+    w.xall_plane = (size_t)g.Mp * c->KE;
+    w.h_plane = (size_t)g.Mp * N_MODEL;
+    w.qkv_plane = (size_t)g.B * c->H * g.Lp * 256;
+    w.o_plane = (size_t)g.Mp * c->HD;
+    w.xall = (__bf16*)take(2 * w.xall_plane * 2);
+    w.hA = (__bf16*)take(2 * w.h_plane * 2);
+    w.hB = (__bf16*)take(2 * w.h_plane * 2);
+    w.F = (__bf16*)take(2 * w.h_plane * 2);
+    w.Q = (__bf16*)take(2 * w.qkv_plane * 2);
+    w.K = (__bf16*)take(2 * w.qkv_plane * 2);
+    w.V = (__bf16*)take(2 * w.qkv_plane * 2);
+    w.O = (__bf16*)take(2 * w.o_plane * 2);
+    w.total = off;
+}
+
+// ------------------------------------------------------------------------------------ launch helpers
+struct ProfScope {
+    egoego_ctx* c;
+    hipStream_t s;
+    bool on;
+    ProfScope(egoego_ctx* c_, int id, hipStream_t s_) : c(c_), s(s_), on(c_->prof_id == id) {
+        if (on) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            (void)hipEventRecord(e, s);
+            c->prof_events.push_back(e);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            (void)hipEventRecord(e, s);
+            c->prof_events.push_back(e);
+        }
+    }
+};
+
+template <class K>
+static hipError_t allow_smem(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// GEMM tile configurations (features x tokens per block):
+//   A: 128 x 128, 4 waves (2x2), wave tile 64 x 64, 2 k-steps per stage   — embed, QKV, FFN-1
+//   B: 512 x  64, 4 waves (4x1), wave tile 128 x 64, 1 k-step per stage   — fc / FFN-2 + residual + LayerNorm
+//   C: 256 x  64, 4 waves (4x1), wave tile 64 x 64, 2 k-steps per stage   — linear_out + DDPM posterior
+template <int NP> using CfgA = GemmCfg<2, 2, 2, 2, 2, NP, false>;
+template <int NP> using CfgAV = GemmCfg<2, 2, 2, 2, 2, NP, true>;
+template <int NP> using CfgB = GemmCfg<4, 2, 4, 1, (NP == 2 ? 1 : 2), NP, false>;
+template <int NP> using CfgC = GemmCfg<2, 2, 4, 1, 2, NP, false>;
+
+template <class C, class Epi>
+static int launch_gemm(const GemmOperands& g, const Epi& epi, hipStream_t s) {
+    auto kern = gemm_kernel<C, Epi>;
+    static bool once = false;
+    if (!once) {
+        HIP_TRY(allow_smem(kern, C::SMEM_BYTES));
+        once = true;
+    }
+    kern<<<dim3(g.nfb * g.ntb), dim3(C::NT), C::SMEM_BYTES, s>>>(g, epi);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int KT, int NP>
+static int launch_attn_kt(const AttnArgs& a, int BH, hipStream_t s) {
+    auto kern = attn_kernel<KT, NP>;
+    constexpr int smem = 2 * KT * NP * 4096;
+    static bool once = false;
+    if (!once) {
+        HIP_TRY(allow_smem(kern, smem));
+        once = true;
+    }
+    kern<<<dim3((KT + 3) / 4, BH), dim3(256), smem, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NP>
+static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
+    switch (KT) {
+        case 1: return launch_attn_kt<1, NP>(a, BH, s);
+        case 2: return launch_attn_kt<2, NP>(a, BH, s);
+        case 4: return launch_attn_kt<4, NP>(a, BH, s);
+        case 7: return launch_attn_kt<7, NP>(a, BH, s);
+    }
+    return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
+}
+
+// ------------------------------------------------------------------------------------ the step
+struct StepIO {
+    const float* row_mask;  // packed [Mp] or nullptr
+    int stop_layer, stop_stage;  // debug early exit (-1: run everything)
+    bool run_out;
+    OutParams out;
+};
+
+template <int NP>
+static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s) {
+    const int Mp = g.Mp, H = c->H, HD = c->HD;
+    // --- embed: start_conv + time token + position embedding (TM:199-216)
+    {
+        ProfScope ps(c, EGOEGO_K_EMBED, s);
+        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / 128, Mp / 128};
+        EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B};
+        if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
+    }
+    if (io.stop_stage == EGOEGO_DBG_EMBED) return 0;
+    for (int li = 0; li < c->cfg.n_dec_layers; ++li) {
+        const LayerDev& L = c->layers[li];
+        const bool last_dbg = (li == io.stop_layer);
+        // --- Q, K, V projections (TM:71-73)
+        {
+            ProfScope ps(c, EGOEGO_K_QKV, s);
+            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / 128, Mp / 128};
+            EpiQK<NP> eqk{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
+            EpiV<NP> ev{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
+            auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
+            static bool once = false;
+            if (!once) {
+                HIP_TRY(allow_smem(kern, CfgA<NP>::SMEM_BYTES));
+                once = true;
+            }
+            kern<<<dim3(go.nfb * go.ntb), dim3(256), CfgA<NP>::SMEM_BYTES, s>>>(go, eqk, ev, 2 * HD / 128);
+            HIP_TRY(hipGetLastError());
+        }
+        if (last_dbg && (io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V))
+            return 0;
+        // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
+        {
+            ProfScope ps(c, EGOEGO_K_ATTN, s);
+            AttnArgs a{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L};
+            if (int r = launch_attn<NP>(a, g.KT, g.B * H, s)) return r;
+        }
+        if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_OUT) return 0;
+        // --- fc + residual + LayerNorm (+ padding mask) (TM:92-93, 135)
+        {
+            ProfScope ps(c, EGOEGO_K_FC_LN, s);
+            GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, Mp / 64};
+            EpiResLN<NP, 4, 64> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+            if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+        }
+        if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_LN) return 0;
+        // --- FFN conv 1 + ReLU (TM:111)
+        {
+            ProfScope ps(c, EGOEGO_K_FFN1, s);
+            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / 128, Mp / 128};
+            EpiTiled<true, NP> e{L.b_1, w.F, w.h_plane, N_MODEL / 16};
+            if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
+        }
+        if (last_dbg && io.stop_stage == EGOEGO_DBG_FFN_HIDDEN) return 0;
+        // --- FFN conv 2 + residual + LayerNorm (+ padding mask) (TM:111-114, 139)
+        {
+            ProfScope ps(c, EGOEGO_K_FFN2_LN, s);
+            GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, Mp / 64};
+            EpiResLN<NP, 4, 64> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
+            if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+        }
+        if (last_dbg && io.stop_stage == EGOEGO_DBG_LAYER_OUT) return 0;
+    }
+    if (io.run_out) {
+        ProfScope ps(c, EGOEGO_K_OUT, s);
+        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, Mp / 64};
+        EpiOut<NP> e{io.out};
+        if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
+    }
+    return 0;
+}
+
+static int run_denoiser(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s) {
+    return c->cfg.precision == EGOEGO_PREC_BF16X3 ? run_denoiser_np<2>(c, g, w, io, s) : run_denoiser_np<1>(c, g, w, io, s);
+}
+
+static int check_ready(const egoego_ctx* c, bool need_sched) {
+    if (!c) return fail(EGOEGO_E_INVALID, "null context");
+    if (!c->have_weights) return fail(EGOEGO_E_STATE, "egoego_load_weights has not been called");
+    if (need_sched && !c->have_sched) return fail(EGOEGO_E_STATE, "egoego_load_schedule has not been called");
+    return 0;
+}
+
+static int prepare(egoego_ctx* c, int B, int T, void* d_ws, size_t ws_bytes, Geometry& g, Workspace& w) {
+    if (int r = make_geometry(c, B, T, g)) return r;
+    if (!d_ws || ((uintptr_t)d_ws & 255)) return fail(EGOEGO_E_WORKSPACE, "workspace must be a 256-byte aligned device pointer");
+    carve(c, g, (char*)d_ws, w);
+    if (ws_bytes < w.total)
+        return fail(EGOEGO_E_WORKSPACE, "workspace too small: %zu bytes given, %zu needed for B=%d T=%d", ws_bytes, w.total, B, T);
+    return 0;
+}
+
+static int pack_inputs(egoego_ctx* c, const Geometry& g, const Workspace& w, const float* d_x, const float* d_xc,
+                       const float* d_row_mask, const float** packed_mask, hipStream_t s) {
+    const size_t n = (size_t)g.Mp * (c->KE / 2);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    k_pack_pose<<<blocks, 256, 0, s>>>(d_x, d_xc, w.xall, w.xall_plane, g.Mp, c->KE, g.Lp, g.T, g.B, c->D, c->DP, 1);
+    HIP_TRY(hipGetLastError());
+    *packed_mask = nullptr;
+    if (d_row_mask) {
+        k_pack_row_mask<<<(g.Mp + 255) / 256, 256, 0, s>>>(d_row_mask, w.row_mask, g.Mp, g.Lp, g.T, g.B);
+        HIP_TRY(hipGetLastError());
+        *packed_mask = w.row_mask;
+    }
+    return 0;
+}
+
+static void base_out_params(const egoego_ctx* c, const Geometry& g, const Workspace& w, OutParams& o) {
+    memset(&o, 0, sizeof o);
+    o.bias = c->b_out;
+    o.xall = w.xall;
+    o.xall_plane = w.xall_plane;
+    o.KE16 = c->KE / 16;
+    o.sched = c->sched;
+    o.t_idx = w.t_idx;
+    o.objective = c->cfg.objective;
+    o.clip = 1;
+    o.Lp = g.Lp; o.T = g.T; o.B = g.B; o.D = c->D; o.DP = c->DP;
+}
+
+// ==================================================================================== C ABI
+extern "C" {
+
+int egoego_abi_version(void) { return EGOEGO_ABI_VERSION; }
+const char* egoego_last_error(void) { return g_err.c_str(); }
+
+int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
+    if (!cfg || !out) return fail(EGOEGO_E_INVALID, "null argument");
+    if (cfg->d_model != 512) return fail(EGOEGO_E_INVALID, "d_model=%d unsupported (LayerNorm-fused GEMM tiles are built for 512)", cfg->d_model);
+    if (cfg->d_k != 256 || cfg->d_v != 256) return fail(EGOEGO_E_INVALID, "d_k=%d d_v=%d unsupported (attention tiles are built for 256)", cfg->d_k, cfg->d_v);
+    if (cfg->n_head < 1 || cfg->n_head > 16) return fail(EGOEGO_E_INVALID, "n_head=%d unsupported", cfg->n_head);
+    if (cfg->n_dec_layers < 1) return fail(EGOEGO_E_INVALID, "n_dec_layers must be >= 1");
+    if (cfg->d_feats < 2 || (cfg->d_feats & 1) || cfg->d_feats > 248)
+        return fail(EGOEGO_E_INVALID, "d_feats=%d unsupported (must be even and <= 248)", cfg->d_feats);
+    if (cfg->max_timesteps < 2 || cfg->num_timesteps < 1) return fail(EGOEGO_E_INVALID, "bad max_timesteps/num_timesteps");
+    if (cfg->objective != EGOEGO_PRED_X0 && cfg->objective != EGOEGO_PRED_NOISE)
+        return fail(EGOEGO_E_INVALID, "unknown objective %d", cfg->objective);
+    if (cfg->precision != EGOEGO_PREC_BF16X3 && cfg->precision != EGOEGO_PREC_BF16X1)
+        return fail(EGOEGO_E_INVALID, "unknown precision %d", cfg->precision);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(EGOEGO_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    egoego_ctx* c = new egoego_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    c->D = cfg->d_feats;
+    c->DP = (int)align_up(c->D, 8);
+    c->KE = (int)align_up(2 * c->DP, 32);
+    c->H = cfg->n_head;
+    c->HD = c->H * 256;
+    c->NOUT = 256;
+    c->S = cfg->num_timesteps;
+    c->have_weights = c->have_sched = false;
+    c->prof_id = -1;
+    c->w_embed = c->w_out = nullptr;
+    *out = c;
+    return 0;
+}
+
+void egoego_ctx_destroy(egoego_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void* p : c->allocs) (void)hipFree(p);
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    delete c;
+}
+
+static int dev_alloc(egoego_ctx* c, void** p, size_t bytes, bool zero, hipStream_t s) {
+    HIP_TRY(hipMalloc(p, bytes));
+    c->allocs.push_back(*p);
+    if (zero) HIP_TRY(hipMemsetAsync(*p, 0, bytes, s));
+    return 0;
+}
+
+static int pack_weight(const float* src, int R, int ncols, int ld, int c0, __bf16* dst, size_t plane, int K16, int r0,
+                       int k0, hipStream_t s) {
+    const size_t n = (size_t)R * (ncols / 2);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    k_pack_rows<<<blocks, 256, 0, s>>>(src, R, ncols, ld, c0, dst, plane, K16, r0, k0, 1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int copy_vec(egoego_ctx* c, float** dst, const float* src, int n, int n_alloc, hipStream_t s) {
+    if (int r = dev_alloc(c, (void**)dst, sizeof(float) * n_alloc, n_alloc != n, s)) return r;
+    HIP_TRY(hipMemcpyAsync(*dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
+    if (!c || !wt || !wt->layers) return fail(EGOEGO_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    // (re)loading frees the previous copies after the stream drained
+    if (c->have_weights) {
+        HIP_TRY(hipStreamSynchronize(s));
+        for (void* p : c->allocs) (void)hipFree(p);
+        c->allocs.clear();
+        c->layers.clear();
+        c->have_weights = c->have_sched = false;
+    }
+    const int HD = c->HD, D = c->D, DP = c->DP, KE = c->KE;
+    int r;
+    // embed: start_conv.weight (512, 2D, 1): input columns [0,D) -> k [0,D), [D,2D) -> k [DP, DP+D)
+    if ((r = dev_alloc(c, (void**)&c->w_embed, (size_t)2 * N_MODEL * KE * 2, true, s))) return r;
+    if ((r = pack_weight(wt->start_conv_w, N_MODEL, D, 2 * D, 0, c->w_embed, (size_t)N_MODEL * KE, KE / 16, 0, 0, s))) return r;
+    if ((r = pack_weight(wt->start_conv_w, N_MODEL, D, 2 * D, D, c->w_embed, (size_t)N_MODEL * KE, KE / 16, 0, DP, s))) return r;
+    if ((r = copy_vec(c, &c->b_embed, wt->start_conv_b, N_MODEL, N_MODEL, s))) return r;
+    const int pe_rows = c->cfg.max_timesteps + 1;
+    if ((r = copy_vec(c, &c->pe, wt->position_vec, pe_rows * N_MODEL, pe_rows * N_MODEL, s))) return r;
+    // linear_out, rows padded to NOUT
+    if ((r = dev_alloc(c, (void**)&c->w_out, (size_t)2 * c->NOUT * N_MODEL * 2, true, s))) return r;
+    if ((r = pack_weight(wt->linear_out_w, D, N_MODEL, N_MODEL, 0, c->w_out, (size_t)c->NOUT * N_MODEL, N_MODEL / 16, 0, 0, s))) return r;
+    if ((r = copy_vec(c, &c->b_out, wt->linear_out_b, D, c->NOUT, s))) return r;
+    c->layers.resize(c->cfg.n_dec_layers);
+    for (int li = 0; li < c->cfg.n_dec_layers; ++li) {
+        const egoego_layer_weights& lw = wt->layers[li];
+        LayerDev& L = c->layers[li];
+        const size_t qkv_plane = (size_t)3 * HD * N_MODEL;
+        if ((r = dev_alloc(c, (void**)&L.w_qkv, 2 * qkv_plane * 2, false, s))) return r;
+        if ((r = pack_weight(lw.w_q, HD, N_MODEL, N_MODEL, 0, L.w_qkv, qkv_plane, N_MODEL / 16, 0, 0, s))) return r;
+        if ((r = pack_weight(lw.w_k, HD, N_MODEL, N_MODEL, 0, L.w_qkv, qkv_plane, N_MODEL / 16, HD, 0, s))) return r;
+        if ((r = pack_weight(lw.w_v, HD, N_MODEL, N_MODEL, 0, L.w_qkv, qkv_plane, N_MODEL / 16, 2 * HD, 0, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.b_qkv, sizeof(float) * 3 * HD, false, s))) return r;
+        HIP_TRY(hipMemcpyAsync(L.b_qkv, lw.b_q, sizeof(float) * HD, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(L.b_qkv + HD, lw.b_k, sizeof(float) * HD, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(L.b_qkv + 2 * HD, lw.b_v, sizeof(float) * HD, hipMemcpyDeviceToDevice, s));
+        if ((r = dev_alloc(c, (void**)&L.w_fc, (size_t)2 * N_MODEL * HD * 2, false, s))) return r;
+        if ((r = pack_weight(lw.w_fc, N_MODEL, HD, HD, 0, L.w_fc, (size_t)N_MODEL * HD, HD / 16, 0, 0, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.w_1, (size_t)2 * N_MODEL * N_MODEL * 2, false, s))) return r;
+        if ((r = pack_weight(lw.w_1, N_MODEL, N_MODEL, N_MODEL, 0, L.w_1, (size_t)N_MODEL * N_MODEL, N_MODEL / 16, 0, 0, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.w_2, (size_t)2 * N_MODEL * N_MODEL * 2, false, s))) return r;
+        if ((r = pack_weight(lw.w_2, N_MODEL, N_MODEL, N_MODEL, 0, L.w_2, (size_t)N_MODEL * N_MODEL, N_MODEL / 16, 0, 0, s))) return r;
+        if ((r = copy_vec(c, &L.b_fc, lw.b_fc, N_MODEL, N_MODEL, s))) return r;
+        if ((r = copy_vec(c, &L.ln1_g, lw.ln1_g, N_MODEL, N_MODEL, s))) return r;
+        if ((r = copy_vec(c, &L.ln1_b, lw.ln1_b, N_MODEL, N_MODEL, s))) return r;
+        if ((r = copy_vec(c, &L.b_1, lw.b_1, N_MODEL, N_MODEL, s))) return r;
+        if ((r = copy_vec(c, &L.b_2, lw.b_2, N_MODEL, N_MODEL, s))) return r;
+        if ((r = copy_vec(c, &L.ln2_g, lw.ln2_g, N_MODEL, N_MODEL, s))) return r;
+        if ((r = copy_vec(c, &L.ln2_b, lw.ln2_b, N_MODEL, N_MODEL, s))) return r;
+    }
+    // time-token table.  Frequencies follow M:69-70: c = log(10000)/(32-1) in double, then
+    // exp(float(k) * float(-c)) in fp32.
+    {
+        float freqs[32];
+        const float cneg = (float)(-(log(10000.0) / 31.0));
+        for (int k = 0; k < 32; ++k) freqs[k] = (float)exp((double)((float)k * cneg));
+        float* d_freqs;
+        if ((r = dev_alloc(c, (void**)&d_freqs, sizeof freqs, false, s))) return r;
+        HIP_TRY(hipMemcpyAsync(d_freqs, freqs, sizeof freqs, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // freqs lives on this stack frame
+        if ((r = dev_alloc(c, (void**)&c->tt_table, sizeof(float) * (size_t)c->S * N_MODEL, false, s))) return r;
+        k_time_table<<<c->S, 256, 0, s>>>(d_freqs, wt->time_mlp1_w, wt->time_mlp1_b, wt->time_mlp3_w, wt->time_mlp3_b,
+                                          c->pe + N_MODEL, c->tt_table);
+        HIP_TRY(hipGetLastError());
+    }
+    c->have_weights = true;
+    return 0;
+}
+
+int egoego_load_schedule(egoego_ctx* c, const egoego_schedule* sc, void* stream) {
+    if (!c || !sc) return fail(EGOEGO_E_INVALID, "null argument");
+    if (!c->have_weights) return fail(EGOEGO_E_STATE, "load weights before the schedule");
+    if (!sc->posterior_mean_coef1 || !sc->posterior_mean_coef2 || !sc->posterior_log_variance_clipped ||
+        !sc->sqrt_recip_alphas_cumprod || !sc->sqrt_recipm1_alphas_cumprod || !sc->alphas_cumprod)
+        return fail(EGOEGO_E_INVALID, "null schedule array");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float> tab((size_t)c->S * 8, 0.f);
+    c->abar_host.assign(sc->alphas_cumprod, sc->alphas_cumprod + c->S);
+    for (int t = 0; t < c->S; ++t) {
+        float* r = &tab[(size_t)t * 8];
+        r[0] = sc->posterior_mean_coef1[t];
+        r[1] = sc->posterior_mean_coef2[t];
+        // M:255-256: nonzero_mask * exp(0.5 * log_variance); no noise at t == 0
+        r[2] = t == 0 ? 0.f : expf(0.5f * sc->posterior_log_variance_clipped[t]);
+        r[3] = sc->sqrt_recip_alphas_cumprod[t];
+        r[4] = sc->sqrt_recipm1_alphas_cumprod[t];
+        r[5] = sc->alphas_cumprod[t];
+    }
+    if (!c->have_sched) {
+        if (int r = dev_alloc(c, (void**)&c->sched, tab.size() * sizeof(float), false, s)) return r;
+    }
+    HIP_TRY(hipMemcpyAsync(c->sched, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->have_sched = true;
+    return 0;
+}
+
+size_t egoego_workspace_bytes(const egoego_ctx* c, int B, int T) {
+    Geometry g;
+    if (!c || make_geometry(c, B, T, g)) return 0;
+    Workspace w;
+    carve(c, g, nullptr, w);
+    return w.total;
+}
+
+int egoego_denoise(egoego_ctx* c, const float* d_x, const float* d_xc, const int64_t* d_t, const float* d_row_mask,
+                   float* d_out, int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
+    if (int r = check_ready(c, false)) return r;
+    if (!d_x || !d_xc || !d_t || !d_out) return fail(EGOEGO_E_INVALID, "null tensor pointer");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Geometry g;
+    Workspace w;
+    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    StepIO io{};
+    if (int r = pack_inputs(c, g, w, d_x, d_xc, d_row_mask, &io.row_mask, s)) return r;
+    k_convert_t<<<(B + 255) / 256, 256, 0, s>>>(d_t, w.t_idx, B, c->S);
+    HIP_TRY(hipGetLastError());
+    io.stop_layer = io.stop_stage = -1;
+    io.run_out = true;
+    base_out_params(c, g, w, io.out);
+    io.out.mode = 0;
+    io.out.out_raw = d_out;
+    return run_denoiser(c, g, w, io, s);
+}
+
+int egoego_p_sample(egoego_ctx* c, float* d_x, const float* d_xc, const int64_t* d_t, const float* d_row_mask,
+                    const float* d_noise, int noise_mode, uint64_t seed, int64_t window_offset, int clip_denoised,
+                    int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
+    if (int r = check_ready(c, true)) return r;
+    if (!d_x || !d_xc || !d_t) return fail(EGOEGO_E_INVALID, "null tensor pointer");
+    if (noise_mode == EGOEGO_NOISE_INJECTED && !d_noise) return fail(EGOEGO_E_INVALID, "noise_mode INJECTED needs d_noise");
+    if (noise_mode < 0 || noise_mode > 2) return fail(EGOEGO_E_INVALID, "unknown noise_mode %d", noise_mode);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Geometry g;
+    Workspace w;
+    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    StepIO io{};
+    if (int r = pack_inputs(c, g, w, d_x, d_xc, d_row_mask, &io.row_mask, s)) return r;
+    k_convert_t<<<(B + 255) / 256, 256, 0, s>>>(d_t, w.t_idx, B, c->S);
+    HIP_TRY(hipGetLastError());
+    io.stop_layer = io.stop_stage = -1;
+    io.run_out = true;
+    base_out_params(c, g, w, io.out);
+    io.out.mode = 1;
+    io.out.x = d_x;
+    io.out.noise = d_noise;
+    io.out.noise_mode = noise_mode;
+    io.out.seed = seed;
+    io.out.window_offset = window_offset;
+    io.out.clip = clip_denoised ? 1 : 0;
+    return run_denoiser(c, g, w, io, s);
+}
+
+int egoego_sample_loop(egoego_ctx* c, float* d_x, const float* d_xc, int t_start, int n_steps, const float* d_noise,
+                       int noise_mode, uint64_t seed, int64_t window_offset, const float* d_prefix, int prefix_len,
+                       int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
+    if (int r = check_ready(c, true)) return r;
+    if (!d_x || !d_xc) return fail(EGOEGO_E_INVALID, "null tensor pointer");
+    if (t_start < 0 || t_start >= c->S || n_steps < 0 || n_steps > t_start + 1)
+        return fail(EGOEGO_E_INVALID, "bad step range: t_start=%d n_steps=%d (num_timesteps=%d)", t_start, n_steps, c->S);
+    if (noise_mode == EGOEGO_NOISE_INJECTED && !d_noise) return fail(EGOEGO_E_INVALID, "noise_mode INJECTED needs d_noise");
+    if (noise_mode < 0 || noise_mode > 2) return fail(EGOEGO_E_INVALID, "unknown noise_mode %d", noise_mode);
+    if (d_prefix && (prefix_len < 1 || prefix_len > T)) return fail(EGOEGO_E_INVALID, "bad prefix_len %d", prefix_len);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Geometry g;
+    Workspace w;
+    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    StepIO io{};
+    // x and x_cond are split/packed ONCE; afterwards the posterior epilogue keeps the embed operand current.
+    if (int r = pack_inputs(c, g, w, d_x, d_xc, nullptr, &io.row_mask, s)) return r;
+    io.stop_layer = io.stop_stage = -1;
+    io.run_out = true;
+    base_out_params(c, g, w, io.out);
+    io.out.mode = 1;
+    io.out.x = d_x;
+    io.out.noise_mode = noise_mode;
+    io.out.seed = seed;
+    io.out.window_offset = window_offset;
+    io.out.prefix = d_prefix;
+    io.out.prefix_len = d_prefix ? prefix_len : 0;
+    const size_t step_elems = (size_t)B * T * c->D;
+    for (int i = 0; i < n_steps; ++i) {
+        const int t = t_start - i;
+        k_fill_t<<<(B + 255) / 256, 256, 0, s>>>(w.t_idx, B, t);
+        HIP_TRY(hipGetLastError());
+        io.out.noise = (noise_mode == EGOEGO_NOISE_INJECTED) ? d_noise + (size_t)i * step_elems : nullptr;
+        if (int r = run_denoiser(c, g, w, io, s)) return r;
+    }
+    return 0;
+}
+
+int egoego_ddim_loop(egoego_ctx* c, float* d_x, const float* d_xc, const int32_t* ts, int n, int B, int T, void* d_ws,
+                     size_t ws_bytes, void* stream) {
+    if (int r = check_ready(c, true)) return r;
+    if (!d_x || !d_xc || !ts || n < 1) return fail(EGOEGO_E_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i)
+        if (ts[i] < 0 || ts[i] >= c->S || (i && ts[i] >= ts[i - 1]))
+            return fail(EGOEGO_E_INVALID, "DDIM timesteps must be strictly descending in [0, %d)", c->S);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Geometry g;
+    Workspace w;
+    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    StepIO io{};
+    if (int r = pack_inputs(c, g, w, d_x, d_xc, nullptr, &io.row_mask, s)) return r;
+    io.stop_layer = io.stop_stage = -1;
+    io.run_out = true;
+    base_out_params(c, g, w, io.out);
+    io.out.mode = 2;
+    io.out.x = d_x;
+    for (int i = 0; i < n; ++i) {
+        k_fill_t<<<(B + 255) / 256, 256, 0, s>>>(w.t_idx, B, ts[i]);
+        HIP_TRY(hipGetLastError());
+        io.out.ddim_abar_prev = (i + 1 < n) ? c->abar_host[ts[i + 1]] : 1.0f;
+        if (int r = run_denoiser(c, g, w, io, s)) return r;
+    }
+    return 0;
+}
+
+int egoego_rot6d_to_matrix(const float* d_in, float* d_out, int64_t n, void* stream) {
+    if (n < 0 || (n && (!d_in || !d_out))) return fail(EGOEGO_E_INVALID, "bad argument");
+    if (n == 0) return 0;
+    const int64_t blocks = (n + 255) / 256;
+    k_rot6d_to_matrix<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, (hipStream_t)stream>>>(d_in, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int egoego_profile_begin(egoego_ctx* c, int kernel_id) {
+    if (!c || kernel_id < 0 || kernel_id >= EGOEGO_K_COUNT) return fail(EGOEGO_E_INVALID, "bad kernel id");
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    c->prof_events.clear();
+    c->prof_id = kernel_id;
+    return 0;
+}
+
+int egoego_profile_end(egoego_ctx* c, double* mean_us, int* launches) {
+    if (!c || !mean_us || !launches) return fail(EGOEGO_E_INVALID, "null argument");
+    c->prof_id = -1;
+    const size_t n = c->prof_events.size() / 2;
+    double total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(c->prof_events[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+        total += ms;
+    }
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    c->prof_events.clear();
+    *launches = (int)n;
+    *mean_us = n ? total * 1000.0 / (double)n : 0.0;
+    return 0;
+}
+
+int egoego_debug_stage(egoego_ctx* c, const float* d_x, const float* d_xc, const int64_t* d_t, const float* d_row_mask,
+                       int layer, int stage, float* d_out, int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
+    if (int r = check_ready(c, false)) return r;
+    if (!d_x || !d_xc || !d_t || !d_out) return fail(EGOEGO_E_INVALID, "null tensor pointer");
+    if (stage < EGOEGO_DBG_EMBED || stage > EGOEGO_DBG_LAYER_OUT || layer < 0 || layer >= c->cfg.n_dec_layers)
+        return fail(EGOEGO_E_INVALID, "bad layer/stage");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Geometry g;
+    Workspace w;
+    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    StepIO io{};
+    if (int r = pack_inputs(c, g, w, d_x, d_xc, d_row_mask, &io.row_mask, s)) return r;
+    k_convert_t<<<(B + 255) / 256, 256, 0, s>>>(d_t, w.t_idx, B, c->S);
+    HIP_TRY(hipGetLastError());
+    io.stop_layer = layer;
+    io.stop_stage = stage;
+    io.run_out = false;
+    if (int r = run_denoiser(c, g, w, io, s)) return r;
+    const int lo = c->cfg.precision == EGOEGO_PREC_BF16X3;
+    const int L = g.L;
+    switch (stage) {
+        case EGOEGO_DBG_EMBED:
+        case EGOEGO_DBG_LAYER_OUT:
+            k_unpack_tiled<<<2048, 256, 0, s>>>(w.hA, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
+            break;
+        case EGOEGO_DBG_ATTN_LN:
+            k_unpack_tiled<<<2048, 256, 0, s>>>(w.hB, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
+            break;
+        case EGOEGO_DBG_FFN_HIDDEN:
+            k_unpack_tiled<<<2048, 256, 0, s>>>(w.F, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
+            break;
+        case EGOEGO_DBG_ATTN_OUT:
+            k_unpack_tiled<<<2048, 256, 0, s>>>(w.O, w.o_plane, c->HD, g.Lp, L, B, d_out, lo);
+            break;
+        case EGOEGO_DBG_Q:
+            k_unpack_qk<<<2048, 256, 0, s>>>(w.Q, w.qkv_plane, c->H, g.Lp, L, B, d_out, lo);
+            break;
+        case EGOEGO_DBG_K:
+            k_unpack_qk<<<2048, 256, 0, s>>>(w.K, w.qkv_plane, c->H, g.Lp, L, B, d_out, lo);
+            break;
+        case EGOEGO_DBG_V:
+            k_unpack_v<<<2048, 256, 0, s>>>(w.V, w.qkv_plane, c->H, g.Lp, L, B, d_out, lo);
+            break;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,590 @@
+// gemm.h — split-bf16 MFMA GEMM over fragment-tiled operands, with fused epilogues.
+//
+// Every Linear / Conv1d(k=1) of the denoiser (TM:45-47,55,102-103,179; M:102) is
+//     out[token][feature] = sum_k act[token][k] * W[feature][k]  (+ bias, + fused tail)
+// Both operands are K-contiguous, so both are stored fragment-tiled (common.h) and both are
+// loaded with the same lane-linear 16-byte reads.  The MFMA is issued "swapped":
+//     D[feature][token] = W_frag (A operand, rows = features) x act_frag (B operand, cols = tokens)
+// so that in the accumulator a lane owns ONE token (lane & 31) and its registers walk the
+// features in groups of 4 consecutive ones.  Consequences:
+//   * LayerNorm's reduction over features is in-lane (+1 cross-half shuffle, + LDS across the
+//     waves that split the feature dimension) — no 32-lane butterflies;
+//   * epilogues store 8 contiguous bytes (4 bf16) per lane straight into the next kernel's
+//     fragment-tiled operand;
+//   * the V projection alone is issued un-swapped (ACT_ROWS) so that V lands transposed and
+//     key-permuted exactly as the PV MFMA of attention.h consumes it.
+//
+// Pipeline: global -> registers (next stage, in flight during the MFMAs) -> LDS (double buffered),
+// one __syncthreads per stage.  With NP == 2 each fragment pair costs three MFMAs
+// (lo*hi, hi*lo, hi*hi).
+#pragma once
+#include "common.h"
+
+struct GemmOperands {
+    const __bf16* w;  // weights, fragment-tiled [N][K]; lo plane at w + w_plane
+    size_t w_plane;
+    const __bf16* a;  // activations, fragment-tiled [Mp][K]; lo plane at a + a_plane
+    size_t a_plane;
+    int K16;  // K / 16
+    int nfb;  // feature blocks in the grid
+    int ntb;  // token blocks in the grid
+};
+
+// Blocks that share an activation tile (same token block, different feature blocks) are made
+// consecutive in the remapped id and land on ONE XCD (hardware places block b on XCD b % 8), so the
+// tile is fetched into one L2 instead of eight.  Bijective for any grid size.
+EG_D int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int FT_, int TT_, int NWF_, int NWT_, int KS_, int NP_, bool ACT_ROWS_>
+struct GemmCfg {
+    static constexpr int FT = FT_, TT = TT_, NWF = NWF_, NWT = NWT_, KS = KS_, NP = NP_;
+    static constexpr bool ACT_ROWS = ACT_ROWS_;
+    static constexpr int NW = NWF * NWT, NT = NW * 64;
+    static constexpr int WT = NWF * FT;  // weight (feature) tiles per block
+    static constexpr int AT = NWT * TT;  // activation (token) tiles per block
+    static constexpr int BF = WT * 32, BT = AT * 32;
+    static constexpr int NBLK = (WT + AT) * NP * KS;  // 1 KiB fragment blocks per stage
+    static constexpr int NCH = NBLK / NW;             // 16-byte chunks per thread per stage
+    static constexpr int STAGE_BYTES = NBLK * 1024;
+    static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+    static_assert(NBLK % NW == 0, "stage blocks must divide evenly over the waves");
+};
+
+template <class C, class Epi>
+struct GemmBody {
+    static __device__ void run(const GemmOperands& g, const Epi& epi, int fblk, int tblk, char* smem) {
+        constexpr int FT = C::FT, TT = C::TT, KS = C::KS, NP = C::NP, WT = C::WT, AT = C::AT, NW = C::NW;
+        constexpr int NCH = C::NCH;
+        const int wave = wave_id_uniform();
+        const int lane = threadIdx.x & 63;
+        const int wf = wave % C::NWF, wt = wave / C::NWF;
+
+        // Per-thread source pointers of this stage's chunks (wave-uniform base + lane).
+        const u32x4* gp[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int blk = j * NW + wave;
+            const int ks = blk % KS, t2 = blk / KS;
+            const u32x4* base;
+            if (t2 < WT * NP) {
+                const int p = t2 / WT, i = t2 % WT;
+                base = (const u32x4*)(g.w + (size_t)p * g.w_plane) + ((size_t)(fblk * WT + i) * g.K16 + ks) * 64;
+            } else {
+                const int t3 = t2 - WT * NP;
+                const int p = t3 / AT, i = t3 % AT;
+                base = (const u32x4*)(g.a + (size_t)p * g.a_plane) + ((size_t)(tblk * AT + i) * g.K16 + ks) * 64;
+            }
+            gp[j] = base + lane;
+        }
+
+        f32x16 acc[FT][TT];
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        const int ns = g.K16 / KS;
+        auto compute = [&](int buf) {
+            const char* sb = smem + (size_t)buf * C::STAGE_BYTES + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 wh[FT], wl[FT], ah[TT], al[TT];
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    wh[i] = *(const bf16x8*)(sb + ((0 * WT + wf * FT + i) * KS + ks) * 1024);
+                    if (NP == 2) wl[i] = *(const bf16x8*)(sb + ((1 * WT + wf * FT + i) * KS + ks) * 1024);
+                }
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    ah[j] = *(const bf16x8*)(sb + ((WT * NP + 0 * AT + wt * TT + j) * KS + ks) * 1024);
+                    if (NP == 2) al[j] = *(const bf16x8*)(sb + ((WT * NP + 1 * AT + wt * TT + j) * KS + ks) * 1024);
+                }
+#pragma unroll
+                for (int i = 0; i < FT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j) {
+                        if (C::ACT_ROWS) {
+                            if (NP == 2) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], wh[i], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], wl[i], acc[i][j], 0, 0, 0);
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], wh[i], acc[i][j], 0, 0, 0);
+                        } else {
+                            if (NP == 2) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], ah[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], al[j], acc[i][j], 0, 0, 0);
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], ah[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+        };
+        {
+            u32x4 st[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) st[j] = gp[j][0];
+            char* dst = smem + ((size_t)wave * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * NW * 1024) = st[j];
+        }
+        __syncthreads();
+        // steady state: stage s+1 travels global -> registers while stage s feeds the MFMAs
+        for (int s = 0; s + 1 < ns; ++s) {
+            const int buf = s & 1;
+            u32x4 st[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) st[j] = gp[j][(size_t)(s + 1) * KS * 64];
+            compute(buf);
+            char* dst = smem + (size_t)(buf ^ 1) * C::STAGE_BYTES + ((size_t)wave * 64 + lane) * 16;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * NW * 1024) = st[j];
+            __syncthreads();
+        }
+        compute((ns - 1) & 1);
+        __syncthreads();
+
+        const int f0 = (fblk * WT + wf * FT) * 32;
+        const int t0 = (tblk * AT + wt * TT) * 32;
+        epi.template run<FT, TT>(acc, f0, t0, lane, wf, wt, smem);
+    }
+};
+
+template <class C, class Epi>
+__global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands g, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    GemmBody<C, Epi>::run(g, epi, lid % g.nfb, lid / g.nfb, smem);
+}
+
+// Q/K feature blocks run swapped, V feature blocks un-swapped; the branch is block-uniform.
+template <class CQK, class EpiQK, class CV, class EpiV>
+__global__ __launch_bounds__(CQK::NT) void qkv_kernel(GemmOperands g, EpiQK eqk, EpiV ev, int n_qk_fblocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int fblk = lid % g.nfb, tblk = lid / g.nfb;
+    if (fblk < n_qk_fblocks)
+        GemmBody<CQK, EpiQK>::run(g, eqk, fblk, tblk, smem);
+    else
+        GemmBody<CV, EpiV>::run(g, ev, fblk, tblk, smem);
+}
+
+// =================================================================================== epilogues
+// Swapped accumulator geometry used below: for acc[ft][tt][r] of lane l (hf = l >> 5, col = l & 31)
+//   token   m = t0 + tt*32 + col
+//   feature f = f0 + ft*32 + 8*(r>>2) + 4*hf + (r&3)          (4 consecutive features per r>>2)
+
+// bias (+ReLU) -> fragment-tiled split-bf16 [Mp][N].  FFN first conv (TM:111 inner).
+template <bool RELU, int NP>
+struct EpiTiled {
+    const float* bias;
+    __bf16* out;
+    size_t out_plane;
+    int N16;
+    template <int FT, int TT>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
+        const int hf = lane >> 5, col = lane & 31;
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = f0 + i * 32 + 8 * g + 4 * hf;
+                const float4 b = *(const float4*)(bias + f);
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    const int m = t0 + j * 32 + col;
+                    float v[4] = {acc[i][j][4 * g + 0] + b.x, acc[i][j][4 * g + 1] + b.y,
+                                  acc[i][j][4 * g + 2] + b.z, acc[i][j][4 * g + 3] + b.w};
+                    if (RELU) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                    }
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    const size_t idx = tiled_index(m, f, N16);
+                    *(uint2*)(out + idx) = hi;
+                    if (NP == 2) *(uint2*)(out + out_plane + idx) = lo;
+                }
+            }
+    }
+};
+
+// Q and K projections (TM:71-72): bias, Q pre-scaled by 1/temperature (TM:52,76), written per
+// (batch, head) as the attention kernel's fragment-tiled operands [b][h][L/32][dk/16][2][32][8].
+template <int NP>
+struct EpiQK {
+    const float* bias;  // [3*HD]
+    __bf16* q;
+    __bf16* k;
+    size_t plane;
+    float qscale;
+    int Lp, H, HD, Mvalid;
+    template <int FT, int TT>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
+        const int hf = lane >> 5, col = lane & 31;
+        const int LT = Lp >> 5;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int m0 = t0 + j * 32;
+            if (m0 >= Mvalid) continue;
+            const int b = m0 / Lp, lt = (m0 % Lp) >> 5;
+#pragma unroll
+            for (int i = 0; i < FT; ++i) {
+                const int fb = f0 + i * 32;
+                const int which = fb / HD, fh = fb % HD;
+                const int h = fh >> 8, d0 = fh & 255;
+                __bf16* dst = which ? k : q;
+                const float sc = which ? 1.0f : qscale;
+                const size_t blk0 = ((size_t)(b * H + h) * LT + lt) * 16;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = d0 + 8 * g + 4 * hf;
+                    const float4 bb = *(const float4*)(bias + fb + 8 * g + 4 * hf);
+                    float v[4] = {(acc[i][j][4 * g + 0] + bb.x) * sc, (acc[i][j][4 * g + 1] + bb.y) * sc,
+                                  (acc[i][j][4 * g + 2] + bb.z) * sc, (acc[i][j][4 * g + 3] + bb.w) * sc};
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    const size_t idx = (((blk0 + (d >> 4)) * 2 + ((d >> 3) & 1)) << 8) + col * 8 + 4 * hf;
+                    *(uint2*)(dst + idx) = hi;
+                    if (NP == 2) *(uint2*)(dst + plane + idx) = lo;
+                }
+            }
+        }
+    }
+};
+
+// V projection (TM:73), un-swapped accumulator: lane owns feature (col), registers walk tokens.
+// Written transposed per (batch, head): [b][h][dv/32][L/16][2][32][8] where inside each group of 16
+// keys, key = 8a + 4b + c sits at slot (hfk = b, e = 4a + c) — the order in which the PV MFMA's
+// B operand (the softmax probabilities, straight out of the S^T accumulator) presents its keys.
+template <int NP>
+struct EpiV {
+    const float* bias;  // [3*HD]
+    __bf16* v;
+    size_t plane;
+    int Lp, H, HD, Mvalid;
+    template <int FT, int TT>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
+        const int hf = lane >> 5, col = lane & 31;
+        const int KG = Lp >> 4;
+#pragma unroll
+        for (int i = 0; i < FT; ++i) {
+            const int f = f0 + i * 32 + col;
+            const int fv = f - 2 * HD;
+            const int h = fv >> 8, dt = (fv & 255) >> 5;
+            const float bf = bias[f];
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                const int m0 = t0 + j * 32;
+                if (m0 >= Mvalid) continue;
+                const int b = m0 / Lp, lt = (m0 % Lp) >> 5;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        __bf16 x, y;
+                        split_bf16(acc[i][j][8 * jj + e] + bf, x, y);
+                        hi[e] = x;
+                        lo[e] = y;
+                    }
+                    const size_t idx = ((((size_t)((b * H + h) * 8 + dt) * KG + (2 * lt + jj)) * 2 + hf) << 8) + col * 8;
+                    *(uint4*)(v + idx) = __builtin_bit_cast(uint4, hi);
+                    if (NP == 2) *(uint4*)(v + plane + idx) = __builtin_bit_cast(uint4, lo);
+                }
+            }
+        }
+    }
+};
+
+// bias + residual + LayerNorm(512) (+ padding-mask row multiply) -> fragment-tiled split-bf16.
+// Output projection of attention (TM:92-93, 135) and second FFN conv (TM:111-114, 139).
+// The block must span all 512 features (NWF * FT * 32 == 512).
+template <int NP, int NWF, int BT>
+struct EpiResLN {
+    const float* bias;
+    const __bf16* res;  // fragment-tiled [Mp][512]
+    size_t res_plane;
+    const float* gamma;
+    const float* beta;
+    const float* row_mask;  // [Mp] or nullptr
+    __bf16* out;
+    size_t out_plane;
+    float eps;
+    template <int FT, int TT>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem) const {
+        static_assert(NWF * FT * 32 == 512, "LayerNorm epilogue needs the whole 512-wide row in the block");
+        const int hf = lane >> 5, col = lane & 31;
+        float* red1 = (float*)smem;        // [NWF][BT]
+        float* red2 = red1 + NWF * BT;     // [NWF][BT]
+        // y = acc + bias + residual
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = f0 + i * 32 + 8 * g + 4 * hf;
+                const float4 b = *(const float4*)(bias + f);
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    const int m = t0 + j * 32 + col;
+                    const size_t idx = tiled_index(m, f, 32);
+                    float r[4];
+                    const uint2 rh = *(const uint2*)(res + idx);
+                    if (NP == 2) {
+                        const uint2 rl = *(const uint2*)(res + res_plane + idx);
+                        unpack4(rh, rl, r);
+                    } else {
+                        unpack4_hi(rh, r);
+                    }
+                    acc[i][j][4 * g + 0] += b.x + r[0];
+                    acc[i][j][4 * g + 1] += b.y + r[1];
+                    acc[i][j][4 * g + 2] += b.z + r[2];
+                    acc[i][j][4 * g + 3] += b.w + r[3];
+                }
+            }
+        // mean over the 512 features of each token
+        float mean[TT], rstd[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+            s += __shfl_xor(s, 32);
+            if (hf == 0) red1[wf * BT + (wt * TT + j) * 32 + col] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWF; ++w) s += red1[w * BT + (wt * TT + j) * 32 + col];
+            mean[j] = s * (1.0f / 512.0f);
+        }
+        // biased variance of the centred values (two-pass, as accurate as the reference's LN)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[i][j][r] - mean[j];
+                    s += d * d;
+                }
+            s += __shfl_xor(s, 32);
+            if (hf == 0) red2[wf * BT + (wt * TT + j) * 32 + col] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWF; ++w) s += red2[w * BT + (wt * TT + j) * 32 + col];
+            rstd[j] = 1.0f / sqrtf(s * (1.0f / 512.0f) + eps);
+        }
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = f0 + i * 32 + 8 * g + 4 * hf;
+                const float4 ga = *(const float4*)(gamma + f);
+                const float4 be = *(const float4*)(beta + f);
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    const int m = t0 + j * 32 + col;
+                    float v[4];
+                    v[0] = (acc[i][j][4 * g + 0] - mean[j]) * rstd[j] * ga.x + be.x;
+                    v[1] = (acc[i][j][4 * g + 1] - mean[j]) * rstd[j] * ga.y + be.y;
+                    v[2] = (acc[i][j][4 * g + 2] - mean[j]) * rstd[j] * ga.z + be.z;
+                    v[3] = (acc[i][j][4 * g + 3] - mean[j]) * rstd[j] * ga.w + be.w;
+                    if (row_mask) {
+                        const float mk = row_mask[m];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] *= mk;
+                    }
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    const size_t idx = tiled_index(m, f, 32);
+                    *(uint2*)(out + idx) = hi;
+                    if (NP == 2) *(uint2*)(out + out_plane + idx) = lo;
+                }
+            }
+    }
+};
+
+// start_conv bias + frozen position embedding, time token in row 0 of every window, zeros in the
+// padding rows (TM:199-216; M:122-123,133).  Row l of a window gets position id l + 1.
+template <int NP>
+struct EpiEmbed {
+    const float* bias;      // [512]
+    const float* pe;        // [max_timesteps + 1][512]
+    const float* tt_table;  // [S][512]: time_mlp(t) + pe[1]
+    const int* t_idx;       // [B]
+    __bf16* out;
+    size_t out_plane;
+    int Lp, T, B;
+    template <int FT, int TT>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
+        const int hf = lane >> 5, col = lane & 31;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int m = t0 + j * 32 + col;
+            const int b = m / Lp, lw = m % Lp;
+            const int kind = (b >= B || lw > T) ? 0 : (lw == 0 ? 1 : 2);
+            const float* trow = (kind == 1) ? tt_table + (size_t)t_idx[b] * 512 : nullptr;
+            const float* prow = (kind == 2) ? pe + (size_t)(lw + 1) * 512 : nullptr;
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = f0 + i * 32 + 8 * g + 4 * hf;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (kind == 1) {
+                        const float4 t4 = *(const float4*)(trow + f);
+                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                    } else if (kind == 2) {
+                        const float4 b4 = *(const float4*)(bias + f);
+                        const float4 p4 = *(const float4*)(prow + f);
+                        v[0] = (acc[i][j][4 * g + 0] + b4.x) + p4.x;
+                        v[1] = (acc[i][j][4 * g + 1] + b4.y) + p4.y;
+                        v[2] = (acc[i][j][4 * g + 2] + b4.z) + p4.z;
+                        v[3] = (acc[i][j][4 * g + 3] + b4.w) + p4.w;
+                    }
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    const size_t idx = tiled_index(m, f, 32);
+                    *(uint2*)(out + idx) = hi;
+                    if (NP == 2) *(uint2*)(out + out_plane + idx) = lo;
+                }
+        }
+    }
+};
+
+// linear_out (M:139) fused with the whole DDPM tail (M:235-256): x0 from the objective, clamp,
+// posterior mean, noise, in-place x update, optional prefix in-painting (M:395-397), and the
+// re-split of the new x into the embed GEMM's operand for the next step.
+struct OutParams {
+    const float* bias;     // [256] zero padded
+    int mode;              // 0: raw model output -> out_raw; 1: posterior update of x
+    float* x;              // [B][T][D] in/out (mode 1)
+    float* out_raw;        // [B][T][D] (mode 0)
+    __bf16* xall;          // fragment-tiled [Mp][KE]
+    size_t xall_plane;
+    int KE16;
+    const float* sched;    // [S][8]: c1, c2, sigma, sqrt_recip, sqrt_recipm1, abar, -, -
+    const int* t_idx;      // [B]
+    const float* noise;    // [B][T][D] or nullptr
+    int noise_mode;        // EGOEGO_NOISE_*
+    uint64_t seed;
+    int64_t window_offset;
+    int clip;
+    int objective;         // 1 = pred_x0
+    const float* prefix;   // [B][prefix_len][D] or nullptr
+    int prefix_len;
+    // DDIM (mode 2): x <- sqrt(abar_prev) * x0 + sqrt(1 - abar_prev) * eps, abar_prev given per call
+    float ddim_abar_prev;
+    int Lp, T, B, D, DP;
+};
+
+template <int NP>
+struct EpiOut {
+    OutParams p;
+    // one group = 4 consecutive features f..f+3 of one frame
+    __device__ void group(const float (&o)[4], int f, int m, int b, int frame, size_t row, int t, float c1, float c2,
+                          float sigma, float srec, float srecm1, float abar) const {
+        if (p.mode == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c += 2)
+                if (f + c < p.D) *(float2*)(p.out_raw + row + f + c) = make_float2(o[c], o[c + 1]);
+            return;
+        }
+        float xt[4] = {0.f, 0.f, 0.f, 0.f}, nz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; c += 2)
+            if (f + c < p.D) {
+                const float2 v = *(const float2*)(p.x + row + f + c);
+                xt[c] = v.x;
+                xt[c + 1] = v.y;
+            }
+        if (p.mode == 1 && sigma != 0.f) {
+            if (p.noise_mode == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; c += 2)
+                    if (f + c < p.D) {
+                        const float2 v = *(const float2*)(p.noise + row + f + c);
+                        nz[c] = v.x;
+                        nz[c + 1] = v.y;
+                    }
+            } else if (p.noise_mode == 1) {
+                philox_normal4(p.seed, (uint32_t)(f >> 2), (uint32_t)frame, (uint32_t)(p.window_offset + b), (uint32_t)t, nz);
+            }
+        }
+        float xn[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x0 = (p.objective == 1) ? o[c] : (srec * xt[c] - srecm1 * o[c]);
+            if (p.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            if (p.mode == 1) {
+                const float mean = c1 * x0 + c2 * xt[c];
+                xn[c] = mean + sigma * nz[c];
+            } else {  // DDIM, eta = 0
+                const float eps = (xt[c] - sqrtf(abar) * x0) / sqrtf(fmaxf(1.0f - abar, 1e-20f));
+                xn[c] = sqrtf(p.ddim_abar_prev) * x0 + sqrtf(fmaxf(1.0f - p.ddim_abar_prev, 0.f)) * eps;
+            }
+            if (f + c >= p.D) xn[c] = 0.f;
+        }
+        if (p.prefix && frame < p.prefix_len) {
+            const float* pr = p.prefix + ((size_t)b * p.prefix_len + frame) * p.D;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (f + c < p.D) xn[c] = pr[f + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c += 2)
+            if (f + c < p.D) *(float2*)(p.x + row + f + c) = make_float2(xn[c], xn[c + 1]);
+        uint2 hi, lo;
+        split4(xn, hi, lo);
+        const size_t idx = tiled_index(m, f, p.KE16);
+        *(uint2*)(p.xall + idx) = hi;
+        if (NP == 2) *(uint2*)(p.xall + p.xall_plane + idx) = lo;
+    }
+
+    template <int FT, int TT>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
+        const int hf = lane >> 5, col = lane & 31;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int m = t0 + j * 32 + col;
+            const int b = m / p.Lp, lw = m % p.Lp;
+            const bool valid = (b < p.B) && (lw >= 1) && (lw <= p.T);
+            const int frame = lw - 1;
+            const size_t row = valid ? ((size_t)b * p.T + frame) * p.D : 0;
+            float c1 = 0.f, c2 = 0.f, sigma = 0.f, srec = 0.f, srecm1 = 0.f, abar = 0.f;
+            int t = 0;
+            if (valid && p.mode != 0) {
+                t = p.t_idx[b];
+                const float* s = p.sched + (size_t)t * 8;
+                c1 = s[0]; c2 = s[1]; sigma = s[2]; srec = s[3]; srecm1 = s[4]; abar = s[5];
+            }
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = f0 + i * 32 + 8 * g + 4 * hf;
+                    if (valid && f < p.DP) {
+                        const float4 b4 = *(const float4*)(p.bias + f);
+                        const float o[4] = {acc[i][j][4 * g + 0] + b4.x, acc[i][j][4 * g + 1] + b4.y,
+                                            acc[i][j][4 * g + 2] + b4.z, acc[i][j][4 * g + 3] + b4.w};
+                        group(o, f, m, b, frame, row, t, c1, c2, sigma, srec, srecm1, abar);
+                    }
+                }
+        }
+    }
+};

@@ -1,0 +1,180 @@
+// pointwise.h — HBM-bound helpers around the GEMM/attention chain: operand packing, the
+// time-token table, timestep plumbing, 6D->rotation-matrix, and debug unpacking.
+#pragma once
+#include "common.h"
+
+// fp32 row-major [R][ld] (columns c0 .. c0+ncols) -> fragment-tiled split-bf16 planes, written at
+// (row r0 + r, column k0 + c) and scaled by `scale`.  The destination is pre-zeroed by the caller,
+// so padding rows/columns stay zero.  One thread per PAIR of columns (ncols must be even).
+__global__ void k_pack_rows(const float* __restrict__ src, int R, int ncols, int ld, int c0, __bf16* dst,
+                            size_t dst_plane, int K16, int r0, int k0, int write_lo) {
+    const int half = ncols >> 1;
+    const size_t n = (size_t)R * half;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / half), c = (int)(i % half) * 2;
+        const float2 v = *(const float2*)(src + (size_t)r * ld + c0 + c);
+        __bf16 h0, l0, h1, l1;
+        split_bf16(v.x, h0, l0);
+        split_bf16(v.y, h1, l1);
+        const size_t idx = tiled_index(r0 + r, k0 + c, K16);
+        bf16x2 hh = {h0, h1}, ll = {l0, l1};
+        *(bf16x2*)(dst + idx) = hh;
+        if (write_lo) *(bf16x2*)(dst + dst_plane + idx) = ll;
+    }
+}
+
+// Concatenate x and x_cond (M:232) into the embed GEMM's operand: window b occupies rows
+// b*Lp .. b*Lp+Lp-1; row 0 is the (input-less) time-token slot, rows 1..T the frames, the rest
+// padding.  Columns [0, D) = x, [DP, DP + D) = x_cond, everything else zero.  The WHOLE buffer is
+// rewritten, so no memset is needed.  One thread per pair of columns.
+__global__ void k_pack_pose(const float* __restrict__ x, const float* __restrict__ xc, __bf16* dst,
+                            size_t dst_plane, int Mp, int KE, int Lp, int T, int B, int D, int DP, int write_lo) {
+    const int half = KE >> 1;
+    const size_t n = (size_t)Mp * half;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / half), k = (int)(i % half) * 2;
+        const int b = m / Lp, lw = m % Lp;
+        float2 v = make_float2(0.f, 0.f);
+        if (b < B && lw >= 1 && lw <= T) {
+            const size_t row = ((size_t)b * T + (lw - 1)) * D;
+            if (k < D)
+                v = *(const float2*)(x + row + k);
+            else if (k >= DP && k < DP + D)
+                v = *(const float2*)(xc + row + (k - DP));
+        }
+        __bf16 h0, l0, h1, l1;
+        split_bf16(v.x, h0, l0);
+        split_bf16(v.y, h1, l1);
+        const size_t idx = tiled_index(m, k, KE >> 4);
+        bf16x2 hh = {h0, h1}, ll = {l0, l1};
+        *(bf16x2*)(dst + idx) = hh;
+        if (write_lo) *(bf16x2*)(dst + dst_plane + idx) = ll;
+    }
+}
+
+// Time-token table: row t = time_mlp(t) + position_vec[1]  (M:61-73, 111-116, 122-123; TM:202-216:
+// the time token is sequence position 0 and receives position id 1).  All windows of a sampling
+// step share t, and t only takes num_timesteps values, so the 64->256->512 MLP is evaluated once
+// per t at weight-load time instead of B times per step.  One block (256 threads) per t.
+__global__ __launch_bounds__(256) void k_time_table(const float* __restrict__ freqs, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ w3,
+                                                    const float* __restrict__ b3, const float* __restrict__ pe1,
+                                                    float* __restrict__ out) {
+    __shared__ float e[64];
+    __shared__ float h[256];
+    const int t = blockIdx.x, j = threadIdx.x;
+    if (j < 32) {
+        const float ang = (float)t * freqs[j];
+        e[j] = sinf(ang);
+        e[j + 32] = cosf(ang);
+    }
+    __syncthreads();
+    {
+        float acc = 0.f;
+        for (int k = 0; k < 64; ++k) acc = fmaf(e[k], w1[j * 64 + k], acc);
+        acc += b1[j];
+        h[j] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));  // exact-erf GELU (nn.GELU default)
+    }
+    __syncthreads();
+    for (int o = j; o < 512; o += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k) acc = fmaf(h[k], w3[o * 256 + k], acc);
+        out[(size_t)t * 512 + o] = (acc + b3[o]) + pe1[o];
+    }
+}
+
+// torch.long timesteps -> clamped int32 (the kernels index tables with it).
+__global__ void k_convert_t(const int64_t* __restrict__ t, int* __restrict__ out, int B, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        long long v = t[i];
+        v = v < 0 ? 0 : (v >= S ? S - 1 : v);
+        out[i] = (int)v;
+    }
+}
+
+__global__ void k_fill_t(int* __restrict__ out, int B, int value) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) out[i] = value;
+}
+
+// Padding mask [B][T+1] -> one multiplier per padded token row.
+__global__ void k_pack_row_mask(const float* __restrict__ mask, float* __restrict__ out, int Mp, int Lp, int T, int B) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < Mp) {
+        const int b = m / Lp, lw = m % Lp;
+        out[m] = (b < B && lw <= T) ? mask[(size_t)b * (T + 1) + lw] : 0.f;
+    }
+}
+
+// 6D -> rotation matrix (Zhou et al. 2019 as pytorch3d.transforms.rotation_6d_to_matrix defines it;
+// call site M:493): b1 = a1/|a1|, b2 = (a2 - <b1,a2> b1)/|.|, b3 = b1 x b2, rows (b1, b2, b3).
+// Norms are clamped at 1e-12 like F.normalize.
+__global__ void k_rot6d_to_matrix(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float2* p = (const float2*)(in + i * 6);
+        const float2 v0 = p[0], v1 = p[1], v2 = p[2];
+        const float a1x = v0.x, a1y = v0.y, a1z = v1.x, a2x = v1.y, a2y = v2.x, a2z = v2.y;
+        const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+        const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+        const float dt = b1x * a2x + b1y * a2y + b1z * a2z;
+        const float cx = a2x - dt * b1x, cy = a2y - dt * b1y, cz = a2z - dt * b1z;
+        const float n2 = fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-12f);
+        const float b2x = cx / n2, b2y = cy / n2, b2z = cz / n2;
+        float* o = out + i * 9;
+        o[0] = b1x; o[1] = b1y; o[2] = b1z;
+        o[3] = b2x; o[4] = b2y; o[5] = b2z;
+        o[6] = b1y * b2z - b1z * b2y;
+        o[7] = b1z * b2x - b1x * b2z;
+        o[8] = b1x * b2y - b1y * b2x;
+    }
+}
+
+// ---------------------------------------------------------------- debug / test-only unpackers
+// fragment-tiled [Mp][N] -> fp32 [B][L][N] (drops the padding rows).
+__global__ void k_unpack_tiled(const __bf16* __restrict__ src, size_t plane, int N, int Lp, int L, int B,
+                               float* __restrict__ out, int use_lo) {
+    const size_t n = (size_t)B * L * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i % N);
+        const size_t bl = i / N;
+        const int l = (int)(bl % L), b = (int)(bl / L);
+        const size_t idx = tiled_index(b * Lp + l, f, N >> 4);
+        float v = (float)src[idx];
+        if (use_lo) v += (float)src[plane + idx];
+        out[i] = v;
+    }
+}
+
+// Q/K operand [b][h][Lp/32][16][2][32][8] -> fp32 [B][H][L][256].
+__global__ void k_unpack_qk(const __bf16* __restrict__ src, size_t plane, int H, int Lp, int L, int B,
+                            float* __restrict__ out, int use_lo) {
+    const size_t n = (size_t)B * H * L * 256;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i & 255);
+        const size_t r = i >> 8;
+        const int l = (int)(r % L);
+        const size_t bh = r / L;
+        const size_t idx = bh * (size_t)Lp * 256 + tiled_index(l, d, 16);
+        float v = (float)src[idx];
+        if (use_lo) v += (float)src[plane + idx];
+        out[i] = v;
+    }
+}
+
+// V operand [b][h][8][Lp/16][2][32][8] (transposed, key-permuted) -> fp32 [B][H][L][256].
+__global__ void k_unpack_v(const __bf16* __restrict__ src, size_t plane, int H, int Lp, int L, int B,
+                           float* __restrict__ out, int use_lo) {
+    const size_t n = (size_t)B * H * L * 256;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i & 255);
+        const size_t r = i >> 8;
+        const int key = (int)(r % L);
+        const size_t bh = r / L;
+        const int k16 = key & 15, a = k16 >> 3, bb = (k16 >> 2) & 1, c = k16 & 3;
+        const size_t idx = ((((bh * 8 + (d >> 5)) * (size_t)(Lp >> 4) + (key >> 4)) * 2 + bb) << 8) + (d & 31) * 8 + 4 * a + c;
+        float v = (float)src[idx];
+        if (use_lo) v += (float)src[plane + idx];
+        out[i] = v;
+    }
+}

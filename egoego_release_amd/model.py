@@ -1,0 +1,364 @@
+"""Python surface of the reference's stage-2 diffusion module, backed by the HIP library.
+
+Mirrors the reference interface this path exposes (names, argument meaning, error behaviour):
+  CondGaussianDiffusion            /root/reference/egoego/model/transformer_cond_diffusion_model.py:143
+    .sample / .p_sample_loop / .p_sample / .p_mean_variance / .q_posterior / .predict_start_from_noise
+  TransformerDiffusionModel        ...:75   (parameter container; `denoise_fn`)
+  Decoder & friends                /root/reference/egoego/model/transformer_module.py:36-225
+so that `trainer.ema.ema_model.sample(x_start, cond_mask)` keeps working and reference checkpoints
+load key-for-key (state_dict layout in SURVEY.md §8b).
+
+The nn.Modules below hold parameters only.  Every SAMPLING method runs on the HIP library and raises
+if it is unavailable or the tensors are not on a ROCm device — there is no PyTorch/CPU fallback.
+The plain-PyTorch `forward` of the parameter containers exists solely for the training loss
+(`p_losses` / `forward`), which is outside the accelerated path.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from .engine import HipEngine
+from .synthetic import sinusoid_position_table
+
+
+# ------------------------------------------------------------------------- parameter containers
+class SinusoidalPosEmb(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, t):
+        half = self.dim // 2
+        freqs = torch.exp(torch.arange(half, device=t.device) * -(math.log(10000) / (half - 1)))
+        ang = t[:, None] * freqs[None, :]
+        return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, n_head, d_model, d_k, d_v):
+        super().__init__()
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.w_q = nn.Linear(d_model, n_head * d_k)
+        self.w_k = nn.Linear(d_model, n_head * d_k)
+        self.w_v = nn.Linear(d_model, n_head * d_v)
+        for lin, dd in ((self.w_q, d_k), (self.w_k, d_k), (self.w_v, d_v)):
+            nn.init.normal_(lin.weight, mean=0, std=np.sqrt(2.0 / (d_model + dd)))
+        self.fc = nn.Linear(n_head * d_v, d_model)
+        nn.init.xavier_normal_(self.fc.weight)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.p_drop = 0.1
+
+    def forward(self, h):
+        B, L, _ = h.shape
+        q = self.w_q(h).view(B, L, self.n_head, self.d_k).transpose(1, 2)
+        k = self.w_k(h).view(B, L, self.n_head, self.d_k).transpose(1, 2)
+        v = self.w_v(h).view(B, L, self.n_head, self.d_v).transpose(1, 2)
+        p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(self.d_k), dim=-1)
+        p = F.dropout(p, self.p_drop, self.training)
+        o = (p @ v).transpose(1, 2).reshape(B, L, self.n_head * self.d_v)
+        return self.layer_norm(F.dropout(self.fc(o), self.p_drop, self.training) + h)
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_in, d_hid):
+        super().__init__()
+        self.w_1 = nn.Conv1d(d_in, d_hid, 1)
+        self.w_2 = nn.Conv1d(d_hid, d_in, 1)
+        self.layer_norm = nn.LayerNorm(d_in)
+        self.p_drop = 0.1
+
+    def forward(self, h):
+        y = F.linear(F.relu(F.linear(h, self.w_1.weight[:, :, 0], self.w_1.bias)), self.w_2.weight[:, :, 0], self.w_2.bias)
+        return self.layer_norm(F.dropout(y, self.p_drop, self.training) + h)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d_model, n_head, d_k, d_v):
+        super().__init__()
+        self.self_attn = MultiHeadAttention(n_head, d_model, d_k, d_v)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_model)
+
+    def forward(self, h, keep):
+        h = self.self_attn(h)
+        if keep is not None:
+            h = h * keep
+        h = self.pos_ffn(h)
+        return h if keep is None else h * keep
+
+
+class Decoder(nn.Module):
+    def __init__(self, d_feats, d_model, n_layers, n_head, d_k, d_v, max_timesteps):
+        super().__init__()
+        self.start_conv = nn.Conv1d(d_feats, d_model, 1)
+        self.position_vec = nn.Embedding.from_pretrained(sinusoid_position_table(max_timesteps + 1, d_model), freeze=True)
+        self.layer_stack = nn.ModuleList([DecoderLayer(d_model, n_head, d_k, d_v) for _ in range(n_layers)])
+
+    def forward(self, x_all, time_token, keep):
+        e = F.linear(x_all, self.start_conv.weight[:, :, 0], self.start_conv.bias)
+        h = torch.cat((time_token[:, None, :], e), dim=1)
+        h = h + self.position_vec.weight[1:h.shape[1] + 1][None]
+        for layer in self.layer_stack:
+            h = layer(h, keep)
+        return h
+
+
+class TransformerDiffusionModel(nn.Module):
+    def __init__(self, d_feats, d_model, n_dec_layers, n_head, d_k, d_v, max_timesteps):
+        super().__init__()
+        self.d_feats, self.d_model, self.n_head, self.n_dec_layers = d_feats, d_model, n_head, n_dec_layers
+        self.d_k, self.d_v, self.max_timesteps = d_k, d_v, max_timesteps
+        self.motion_transformer = Decoder(d_feats * 2, d_model, n_dec_layers, n_head, d_k, d_v, max_timesteps)
+        self.linear_out = nn.Linear(d_model, d_feats)
+        self.time_mlp = nn.Sequential(SinusoidalPosEmb(64), nn.Linear(64, 256), nn.GELU(), nn.Linear(256, d_model))
+
+    def forward(self, src, noise_t, padding_mask=None):
+        """Plain-PyTorch forward for the TRAINING loss only (autograd); sampling never calls it."""
+        keep = None if padding_mask is None else padding_mask.squeeze(1).unsqueeze(-1).float()
+        h = self.motion_transformer(src, self.time_mlp(noise_t), keep)
+        return self.linear_out(h[:, 1:])
+
+
+# ------------------------------------------------------------------------- schedule
+def _cosine_betas(timesteps, s=0.008):
+    u = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64)
+    abar = torch.cos(((u / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    abar = abar / abar[0]
+    return torch.clip(1 - (abar[1:] / abar[:-1]), 0, 0.999)
+
+
+def _linear_betas(timesteps):
+    scale = 1000 / timesteps
+    return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+
+
+def _extract(a, t, x_shape):
+    return a.gather(-1, t).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+
+class _EngineSlot:
+    """Holds the (non-copyable) HIP context; deep copies (ema_pytorch.EMA) start empty."""
+
+    def __init__(self):
+        self.engine, self.key = None, None
+
+    def __deepcopy__(self, memo):
+        return _EngineSlot()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.engine, self.key = None, None
+
+
+class CondGaussianDiffusion(nn.Module):
+    def __init__(self, d_feats, d_model, n_head, n_dec_layers, d_k, d_v, max_timesteps, out_dim, timesteps=1000,
+                 loss_type="l1", objective="pred_noise", beta_schedule="cosine", p2_loss_weight_gamma=0.0,
+                 p2_loss_weight_k=1, batch_size=None):
+        super().__init__()
+        self.denoise_fn = TransformerDiffusionModel(d_feats=d_feats, d_model=d_model, n_head=n_head, d_k=d_k, d_v=d_v,
+                                                    n_dec_layers=n_dec_layers, max_timesteps=max_timesteps)
+        self.objective = objective
+        self.seq_len = max_timesteps - 1
+        self.out_dim = out_dim
+        if beta_schedule == "linear":
+            betas = _linear_betas(timesteps)
+        elif beta_schedule == "cosine":
+            betas = _cosine_betas(timesteps)
+        else:
+            raise ValueError(f"unknown beta schedule {beta_schedule}")
+        alphas = 1.0 - betas
+        abar = torch.cumprod(alphas, dim=0)
+        abar_prev = F.pad(abar[:-1], (1, 0), value=1.0)
+        self.num_timesteps = int(betas.shape[0])
+        self.loss_type = loss_type
+        post_var = betas * (1.0 - abar_prev) / (1.0 - abar)
+        for name, val in (
+            ("betas", betas), ("alphas_cumprod", abar), ("alphas_cumprod_prev", abar_prev),
+            ("sqrt_alphas_cumprod", torch.sqrt(abar)), ("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - abar)),
+            ("log_one_minus_alphas_cumprod", torch.log(1.0 - abar)), ("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / abar)),
+            ("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / abar - 1)), ("posterior_variance", post_var),
+            ("posterior_log_variance_clipped", torch.log(post_var.clamp(min=1e-20))),
+            ("posterior_mean_coef1", betas * torch.sqrt(abar_prev) / (1.0 - abar)),
+            ("posterior_mean_coef2", (1.0 - abar_prev) * torch.sqrt(alphas) / (1.0 - abar)),
+            ("p2_loss_weight", (p2_loss_weight_k + abar / (1 - abar)) ** -p2_loss_weight_gamma),
+        ):
+            self.register_buffer(name, val.to(torch.float32))
+        # MI355X-specific knobs (not in the reference): operand precision and the noise source.
+        self.hip_precision = _lib.PREC_BF16X3
+        self.sampling_rng = "torch"  # "torch": reference RNG draw order; "philox": in-kernel, shard-invariant
+        self.philox_seed = 0
+        self._slot = _EngineSlot()
+
+    # ------------------------------------------------------------------ HIP engine plumbing
+    def _engine_key(self):
+        dev = self.betas.device
+        return (str(dev), self.hip_precision, self.objective, self.num_timesteps,
+                tuple((p.data_ptr(), p._version) for p in self.denoise_fn.parameters()))
+
+    def hip_engine(self):
+        """The HIP context for the module's current device/weights (packed lazily, re-packed when
+        parameters change or the module moves)."""
+        dev = self.betas.device
+        if dev.type != "cuda":
+            raise _lib.EgoEgoHipError(
+                "CondGaussianDiffusion sampling runs on the MI355X HIP path only: move the module to a ROCm "
+                f"device first (it is on {dev}); there is no CPU fallback")
+        key = self._engine_key()
+        if self._slot.engine is None or self._slot.key != key:
+            if self._slot.engine is not None:
+                self._slot.engine.close()
+            d = self.denoise_fn
+            cfg = dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k,
+                       d_v=d.d_v, max_timesteps=d.max_timesteps, num_timesteps=self.num_timesteps,
+                       objective=self.objective)
+            if self.objective not in ("pred_noise", "pred_x0"):
+                raise ValueError(f"unknown objective {self.objective}")
+            self._slot.engine = HipEngine(cfg, self.state_dict(), dev, self.hip_precision)
+            self._slot.key = key
+        return self._slot.engine
+
+    @staticmethod
+    def _f32c(t):
+        return t.to(torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ reference API (sampling)
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (_extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - _extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = (_extract(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                + _extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return (mean, _extract(self.posterior_variance, t, x_t.shape),
+                _extract(self.posterior_log_variance_clipped, t, x_t.shape))
+
+    @torch.no_grad()
+    def denoise(self, x, t, x_cond, padding_mask=None):
+        """denoise_fn(cat(x, x_cond), t) on the HIP path."""
+        return self.hip_engine().denoise(self._f32c(x), self._f32c(x_cond), t.long().contiguous(), padding_mask)
+
+    def p_mean_variance(self, x, t, x_cond, clip_denoised, padding_mask=None):
+        out = self.denoise(x, t, x_cond, padding_mask)
+        if self.objective == "pred_noise":
+            x_start = self.predict_start_from_noise(x, t=t, noise=out)
+        elif self.objective == "pred_x0":
+            x_start = out
+        else:
+            raise ValueError(f"unknown objective {self.objective}")
+        if clip_denoised:
+            x_start.clamp_(-1.0, 1.0)
+        return self.q_posterior(x_start=x_start, x_t=x, t=t)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, x_cond, clip_denoised=True, padding_mask=None, noise=None):
+        """One ancestral step (fused on the GPU).  `noise=None` draws torch.randn_like(x), exactly
+        where the reference draws it."""
+        eng = self.hip_engine()
+        if noise is None:
+            noise = torch.randn_like(x)
+        out = self._f32c(x).clone()
+        eng.p_sample_(out, self._f32c(x_cond), t.long().contiguous(), self._f32c(noise), padding_mask, clip_denoised)
+        return out
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, x_start, cond_mask, padding_mask=None, noise=None, prefix=None):
+        """x_T ~ N(0,I); x_cond = x_start*(1-m) + m*N(0,I); then num_timesteps ancestral steps.
+
+        noise (optional): dict with 'x_T' [B,T,D], 'cond' [B,T,D] and 'steps' [S,B,T,D] (step 0 = first
+        executed, i.e. t = S-1) to inject the reference's own draws; otherwise torch's generator is
+        consumed in the reference's order (sampling_rng='torch') or the per-step noise is drawn in-kernel
+        (sampling_rng='philox').
+        """
+        eng = self.hip_engine()
+        device = self.betas.device
+        S = self.num_timesteps
+        if noise is not None:
+            x = self._f32c(noise["x_T"].to(device)).clone()
+            cn = noise["cond"].to(device)
+        else:
+            x = torch.randn(shape, device=device)
+            cn = torch.randn_like(x_start).to(x_start.device)
+        x_cond = self._f32c(x_start * (1.0 - cond_mask) + cond_mask * cn)
+        pfx = None if prefix is None else self._f32c(prefix)
+        if noise is not None:
+            steps = noise["steps"]
+            chunk = max(1, min(S, (1 << 28) // max(1, x.numel())))
+            for s0 in range(0, S, chunk):
+                n = min(chunk, S - s0)
+                eng.sample_loop_(x, x_cond, S - 1 - s0, n, noise=self._f32c(steps[s0:s0 + n].to(device)), prefix=pfx)
+        elif padding_mask is not None:
+            b = shape[0]
+            for i in reversed(range(S)):
+                t = torch.full((b,), i, device=device, dtype=torch.long)
+                eng.p_sample_(x, x_cond, t, torch.randn_like(x), padding_mask)
+        elif self.sampling_rng == "philox":
+            eng.sample_loop_(x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=self.philox_seed, prefix=pfx)
+        elif self.sampling_rng == "torch":
+            for i in reversed(range(S)):
+                eng.sample_loop_(x, x_cond, i, 1, noise=torch.randn_like(x)[None], prefix=pfx)
+        else:
+            raise ValueError(f"unknown sampling_rng {self.sampling_rng}")
+        return x
+
+    @torch.no_grad()
+    def sample(self, x_start, cond_mask, padding_mask=None, noise=None):
+        # like the reference (M:528-535): padding_mask is accepted and ignored; eval() then train()
+        self.denoise_fn.eval()
+        res = self.p_sample_loop(x_start.shape, x_start, cond_mask, noise=noise)
+        self.denoise_fn.train()
+        return res
+
+    @torch.no_grad()
+    def ddim_sample(self, x_start, cond_mask, n_steps=50, noise=None):
+        """Deterministic DDIM (eta=0) on a uniform stride of the training timesteps.  Not part of the
+        reference (it only has the full ancestral chain); provided for BASELINE config 4."""
+        eng = self.hip_engine()
+        device = self.betas.device
+        if noise is not None:
+            x, cn = self._f32c(noise["x_T"].to(device)).clone(), noise["cond"].to(device)
+        else:
+            x, cn = torch.randn(x_start.shape, device=device), torch.randn_like(x_start)
+        x_cond = self._f32c(x_start * (1.0 - cond_mask) + cond_mask * cn)
+        ts = sorted({int(round(v)) for v in np.linspace(0, self.num_timesteps - 1, n_steps)}, reverse=True)
+        eng.ddim_loop_(x, x_cond, ts)
+        return x
+
+    # ------------------------------------------------------------------ training half (plain PyTorch)
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return (_extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+                + _extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+    @property
+    def loss_fn(self):
+        if self.loss_type == "l1":
+            return F.l1_loss
+        if self.loss_type == "l2":
+            return F.mse_loss
+        raise ValueError(f"invalid loss type {self.loss_type}")
+
+    def p_losses(self, x_start, cond_mask, t, noise=None, padding_mask=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        x = self.q_sample(x_start=x_start, t=t, noise=noise)
+        x_cond = x_start * (1.0 - cond_mask) + cond_mask * torch.randn_like(x_start)
+        out = self.denoise_fn(torch.cat((x, x_cond), dim=-1), t, padding_mask)
+        if self.objective == "pred_noise":
+            target = noise
+        elif self.objective == "pred_x0":
+            target = x_start
+        else:
+            raise ValueError(f"unknown objective {self.objective}")
+        loss = self.loss_fn(out, target, reduction="none")
+        if padding_mask is not None:
+            loss = loss * padding_mask[:, 0, 1:][:, :, None]
+        loss = loss.flatten(1).mean(dim=1) * _extract(self.p2_loss_weight, t, (loss.shape[0],))
+        return loss.mean()
+
+    def forward(self, x_start, cond_mask, padding_mask=None):
+        t = torch.randint(0, self.num_timesteps, (x_start.shape[0],), device=x_start.device).long()
+        return self.p_losses(x_start, cond_mask, t, padding_mask=padding_mask)
