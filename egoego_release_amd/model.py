@@ -197,7 +197,7 @@ class CondGaussianDiffusion(nn.Module):
     # ------------------------------------------------------------------ HIP engine plumbing
     def _engine_key(self):
         dev = self.betas.device
-        return (str(dev), self.hip_precision, self.objective, self.num_timesteps,
+        return (str(dev), self.hip_precision, self.objective, int(self.betas.shape[0]),
                 tuple((p.data_ptr(), p._version) for p in self.denoise_fn.parameters()))
 
     def hip_engine(self):
@@ -214,7 +214,7 @@ class CondGaussianDiffusion(nn.Module):
                 self._slot.engine.close()
             d = self.denoise_fn
             cfg = dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k,
-                       d_v=d.d_v, max_timesteps=d.max_timesteps, num_timesteps=self.num_timesteps,
+                       d_v=d.d_v, max_timesteps=d.max_timesteps, num_timesteps=int(self.betas.shape[0]),
                        objective=self.objective)
             if self.objective not in ("pred_noise", "pred_x0"):
                 raise ValueError(f"unknown objective {self.objective}")

@@ -1,0 +1,45 @@
+"""The C-ABI library builds for gfx950, loads, and exports exactly what include/egoego_hip.h declares."""
+import os
+import re
+
+from egoego_release_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "egoego_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(egoego_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    build.build()  # no-op when fresh; hipcc cross-compiles without a GPU
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names
+    assert lib.egoego_abi_version() == _lib.ABI_VERSION
+
+
+def test_ctypes_structs_match_header_field_counts():
+    src = open(os.path.join(ROOT, "include", "egoego_hip.h")).read()
+    cfg_body = src[src.index("typedef struct {", src.index("Shapes of TransformerDiffusionModel")):src.index("} egoego_config;")]
+    assert len(re.findall(r"int32_t\s+\w+;", cfg_body)) == len(_lib.Config._fields_)
+    lw_body = src[src.index("typedef struct {", src.index("} egoego_config;")):src.index("} egoego_layer_weights;")]
+    assert len(re.findall(r"const float\*\s*\w+;", lw_body)) == len(_lib.LayerWeights._fields_)
+    sch_body = src[src.index("typedef struct {", src.index("} egoego_weights;")):src.index("} egoego_schedule;")]
+    assert len(re.findall(r"const float\*\s*\w+;", sch_body)) == len(_lib.Schedule._fields_)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.load()
+    except _lib.EgoEgoHipError as e:
+        assert "no CPU or PyTorch fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when the .so is absent")

@@ -1,0 +1,214 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle and the golden vectors the
+reference produced.  Tolerance: the north star's 1e-3 max-abs on pose tensors (written below); the
+split-bf16 path actually lands around 1e-5..1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from egoego_release_amd import ModelConfig, make_weights, make_head_windows, _lib
+from egoego_release_amd.model import CondGaussianDiffusion
+from oracle import egoego_oracle as O
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-3      # BASELINE.json north_star: <= 1e-3 max-abs on the final pose tensor
+STAGE_TOL = 3e-4     # per-stage intermediates (values up to ~6)
+
+
+def _model(T=120, objective="pred_x0", precision=3):
+    cfg = ModelConfig(max_timesteps=T + 1, objective=objective)
+    sd = make_weights(cfg, 0)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m.hip_precision = precision
+    return cfg, sd, m.cuda()
+
+
+def _ref_noise(shape, S, seed=123):
+    """The draws reference.sample() makes after torch.manual_seed(seed) on CPU, in its order."""
+    g = torch.Generator().manual_seed(seed)
+    return {"x_T": torch.randn(shape, generator=g), "cond": torch.randn(shape, generator=g),
+            "steps": torch.stack([torch.randn(shape, generator=g) for _ in range(S)])}
+
+
+def test_stagewise_against_oracle():
+    B, T, H = 2, 120, 4
+    cfg, sd, m = _model(T)
+    eng = m.hip_engine()
+    x_all = torch.randn(B, T, 396, generator=torch.Generator().manual_seed(1120))
+    t = torch.tensor([3, 977])
+    taps = {}
+    with torch.no_grad():
+        O.denoise(sd, x_all, t, taps=taps)
+    xd, xcd, td = x_all[..., :198].contiguous().cuda(), x_all[..., 198:].contiguous().cuda(), t.cuda()
+    L = T + 1
+
+    def err(got, want):
+        return (got.cpu() - want).abs().max().item()
+
+    assert err(eng.debug_stage(xd, xcd, td, 0, "embed"), taps["embed"]) < STAGE_TOL
+    for li in (0, 3):
+        lt = taps[f"layer{li}"]
+        hm = lambda a: a.view(H, B, L, 256).permute(1, 0, 2, 3)
+        assert err(eng.debug_stage(xd, xcd, td, li, "q"), hm(lt["q"]) / 16.0) < STAGE_TOL
+        assert err(eng.debug_stage(xd, xcd, td, li, "k"), hm(lt["k"])) < STAGE_TOL
+        assert err(eng.debug_stage(xd, xcd, td, li, "v"), hm(lt["v"])) < STAGE_TOL
+        for st in ("attn_out", "attn_ln", "ffn_hidden", "out"):
+            assert err(eng.debug_stage(xd, xcd, td, li, st), lt[st]) < STAGE_TOL, (li, st)
+
+
+@pytest.mark.parametrize("T,tags", [(120, ("t0", "t500", "t999", "tmix")), (30, ("t0", "tmix")), (196, ("t0", "tmix"))])
+def test_denoise_against_reference_golden(golden, T, tags):
+    cfg, sd, m = _model(T)
+    x_all = torch.randn(2, T, 396, generator=torch.Generator().manual_seed(int(golden[f"denoise_T{T}_seed"])))
+    x, xc = x_all[..., :198].contiguous().cuda(), x_all[..., 198:].contiguous().cuda()
+    tt = {"t0": [0, 0], "t500": [500, 500], "t999": [999, 999], "tmix": [3, 977]}
+    for tag in tags:
+        y = m.denoise(x, torch.tensor(tt[tag]).cuda(), xc).cpu().numpy()
+        assert np.abs(y - golden[f"denoise_T{T}_{tag}"]).max() < POSE_TOL, tag
+
+
+def test_denoise_padding_mask_golden(golden):
+    cfg, sd, m = _model()
+    x_all = torch.randn(2, 120, 396, generator=torch.Generator().manual_seed(77))
+    pm = torch.ones(2, 1, 121).bool()
+    pm[0, 0, 100:] = False
+    pm[1, 0, 61:] = False
+    y = m.denoise(x_all[..., :198].contiguous().cuda(), torch.tensor([10, 700]).cuda(),
+                  x_all[..., 198:].contiguous().cuda(), padding_mask=pm.cuda()).cpu().numpy()
+    assert np.abs(y - golden["denoise_padmask"]).max() < POSE_TOL
+
+
+@pytest.mark.parametrize("objective", ["pred_x0", "pred_noise"])
+def test_p_sample_golden(golden, objective):
+    cfg, sd, m = _model(objective=objective)
+    g = torch.Generator().manual_seed(2024)
+    x = torch.randn(2, 120, 198, generator=g)
+    xc = torch.randn(2, 120, 198, generator=g)
+    for tval in (500, 0):
+        noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(555))
+        x_in = x.cuda()
+        y = m.p_sample(x_in, torch.full((2,), tval).cuda(), xc.cuda(), noise=noise.cuda())
+        assert torch.equal(x_in.cpu(), x)  # like the reference, p_sample returns a new tensor
+        # pred_noise divides by sqrt(abar): errors are amplified by sqrt_recipm1 (~3.4 at t=500)
+        tol = POSE_TOL if objective == "pred_x0" else 5 * POSE_TOL
+        assert np.abs(y.cpu().numpy() - golden[f"p_sample_{objective}_t{tval}"]).max() < tol, (objective, tval)
+
+
+def test_p_sample_default_noise_uses_torch_generator():
+    cfg, sd, m = _model()
+    g = torch.Generator().manual_seed(8)
+    x, xc = torch.randn(2, 120, 198, generator=g).cuda(), torch.randn(2, 120, 198, generator=g).cuda()
+    t = torch.full((2,), 300).cuda()
+    torch.manual_seed(42)
+    a = m.p_sample(x, t, xc)
+    torch.manual_seed(42)
+    noise = torch.randn_like(x)  # the draw the reference would make at M:253 on this device
+    b = m.p_sample(x, t, xc, noise=noise)
+    assert torch.equal(a, b)
+    want = O.p_sample(sd, O.make_schedule(1000), x.cpu(), t.cpu(), xc.cpu(), noise.cpu())
+    assert (a.cpu() - want).abs().max() < POSE_TOL
+
+
+@pytest.mark.parametrize("tag,B,S", [("b1_s10", 1, 10), ("b2_s50", 2, 50), ("b1_s1000", 1, 1000)])
+def test_sample_chain_against_reference_golden(golden, tag, B, S):
+    """Full sample() with the reference's own noise draws: BASELINE config 1 (B=1, 10 steps), a
+    50-step B=2 chain, and the full 1000-step chain."""
+    cfg, sd, m = _model()
+    m.num_timesteps = S  # the same truncation the reference fixture used
+    xs, cm = make_head_windows(B, 120, seed=11)
+    y = m.sample(xs.cuda(), cm.cuda(), noise=_ref_noise(xs.shape, S)).cpu().numpy()
+    assert m.denoise_fn.training  # sample() leaves the denoiser in train mode like the reference
+    err = np.abs(y - golden[f"sample_{tag}"])
+    assert err.max() < POSE_TOL, (tag, err.max())
+    assert np.abs(y).max() <= 1.0
+
+
+def test_trajectory_stays_close_over_many_steps():
+    """Early divergence check: per-step max error against the oracle over a 25-step window of the chain."""
+    cfg, sd, m = _model()
+    eng = m.hip_engine()
+    sched = O.make_schedule(1000)
+    B, T = 2, 120
+    xs, cm = make_head_windows(B, T, seed=5)
+    nz = _ref_noise(xs.shape, 25, seed=9)
+    x = nz["x_T"].clone()
+    xc = xs * (1 - cm) + cm * nz["cond"]
+    xd, xcd = x.cuda(), xc.cuda()
+    worst = 0.0
+    for i, t in enumerate(range(999, 974, -1)):
+        x = O.p_sample(sd, sched, x, torch.full((B,), t), xc, nz["steps"][i])
+        eng.sample_loop_(xd, xcd, t, 1, noise=nz["steps"][i:i + 1].cuda())
+        worst = max(worst, (xd.cpu() - x).abs().max().item())
+    assert worst < POSE_TOL, worst
+
+
+def test_full_size_properties_b256():
+    """BASELINE config 3 size (B=256, T=120): determinism, shard invariance of the Philox noise,
+    prefix in-painting, finiteness and the final clamp — properties that need no CPU oracle run."""
+    cfg, sd, m = _model()
+    eng = m.hip_engine()
+    B, T = 256, 120
+    xs, cm = make_head_windows(B, T, seed=21)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(xs.shape, generator=g).cuda()
+    xc = (xs * (1 - cm) + cm * torch.randn(xs.shape, generator=g)).cuda()
+    a, b = x0.clone(), x0.clone()
+    eng.sample_loop_(a, xc, 999, 6, noise_mode=_lib.NOISE_PHILOX, seed=3)
+    eng.sample_loop_(b, xc, 999, 6, noise_mode=_lib.NOISE_PHILOX, seed=3)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    c = x0.clone()
+    eng.sample_loop_(c, xc, 999, 6, noise_mode=_lib.NOISE_PHILOX, seed=4)
+    assert not torch.equal(a, c)
+    # a shard of 32 windows at global offset 96 reproduces rows 96:128 of the full batch bit-for-bit
+    sh = x0[96:128].clone()
+    eng.sample_loop_(sh, xc[96:128].contiguous(), 999, 6, noise_mode=_lib.NOISE_PHILOX, seed=3, window_offset=96)
+    assert torch.equal(sh, a[96:128])
+    # the in-kernel noise is standard normal
+    z = torch.zeros_like(x0)
+    eng.sample_loop_(z, xc, 999, 1, noise_mode=_lib.NOISE_PHILOX, seed=11)
+    z0 = torch.zeros_like(x0)
+    eng.sample_loop_(z0, xc, 999, 1, noise_mode=_lib.NOISE_NONE)
+    sigma = float(np.exp(0.5 * O.make_schedule(1000)["posterior_log_variance_clipped"][999].item()))
+    n = ((z - z0) / sigma).flatten()
+    assert abs(n.mean().item()) < 3e-3 and abs(n.std().item() - 1) < 3e-3
+    assert abs((n ** 4).mean().item() - 3) < 0.05
+    # prefix in-painting (sliding-window harness, M:395-397) overwrites the first frames after every step
+    pre = torch.rand(B, 10, 198, generator=torch.Generator().manual_seed(2)).cuda() * 2 - 1
+    d = x0.clone()
+    eng.sample_loop_(d, xc, 999, 3, noise_mode=_lib.NOISE_PHILOX, seed=3, prefix=pre)
+    assert torch.equal(d[:, :10], pre) and not torch.equal(d[:, 10:], x0[:, 10:])
+    # last step of the chain returns clamp(x0): |x| <= 1
+    e = x0.clone()
+    eng.sample_loop_(e, xc, 0, 1, noise_mode=_lib.NOISE_PHILOX, seed=3)
+    assert e.abs().max().item() <= 1.0
+
+
+def test_plain_bf16_mode_runs_and_is_less_accurate():
+    """precision=1 (one MFMA per product) is a reported speed mode; it must run, and it is expected NOT
+    to meet the 1e-3 bar — which is why split-bf16 is the default."""
+    x_all = torch.randn(2, 120, 396, generator=torch.Generator().manual_seed(1120))
+    t = torch.tensor([3, 977])
+    errs = {}
+    for prec in (3, 1):
+        cfg, sd, m = _model(precision=prec)
+        with torch.no_grad():
+            ref = O.denoise(sd, x_all, t)
+        y = m.denoise(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda())
+        errs[prec] = (y.cpu() - ref).abs().max().item()
+    assert errs[3] < 2e-4 and errs[1] < 0.2 and errs[1] > 5 * errs[3], errs
+
+
+def test_error_paths():
+    cfg, sd, m = _model()
+    eng = m.hip_engine()
+    x = torch.zeros(1, 130, 198, device="cuda")
+    with pytest.raises(_lib.EgoEgoHipError, match="exceeds max_timesteps"):
+        eng.denoise(x, x, torch.zeros(1, dtype=torch.long, device="cuda"))
+    x = torch.zeros(1, 120, 198, device="cuda")
+    with pytest.raises(_lib.EgoEgoHipError, match="bad step range"):
+        eng.sample_loop_(x, x, 5, 7)
+    with pytest.raises(_lib.EgoEgoHipError):
+        eng.denoise(x.cpu(), x, torch.zeros(1, dtype=torch.long, device="cuda"))
+    m.objective = "pred_v"
+    with pytest.raises(ValueError, match="unknown objective"):
+        m.hip_engine()

@@ -1,0 +1,112 @@
+"""Host-side model of the fragment-tiled layouts and of the MFMA lane maps the kernels rely on.
+
+A numpy emulation of v_mfma_f32_32x32x16_bf16 (operand/accumulator lane maps as documented for
+gfx950) is used to check, without a GPU, that (a) the fragment-tiled index gives lane-linear operand
+fragments, (b) the "swapped" epilogue index math lands on the right (token, feature), and (c) the
+key permutation written by the V epilogue is the one the S^T accumulator presents to the PV MFMA.
+"""
+import numpy as np
+
+
+def tiled_index(r, k, K16):
+    return ((((r >> 5) * K16 + (k >> 4)) * 2 + ((k >> 3) & 1)) << 8) + ((r & 31) << 3) + (k & 7)
+
+
+def frag_from_tiled(plane, rt, ks, K16):
+    """What a wave reads: lane l takes 8 elements at block_base + 8*l."""
+    base = ((rt * K16 + ks) * 2) << 8
+    return plane[base:base + 512].reshape(64, 8)
+
+
+def mfma_32x32x16(a_frag, b_frag, acc):
+    """a_frag/b_frag: [64 lanes][8]; acc: [64 lanes][16].  A[i][k]: lane = i + 32*(k//8), elem k%8;
+    B[k][j]: lane = j + 32*(k//8); D[i][j]: lane = j + 32*((i%8)//4), reg = (i%4) + 4*(i//8)."""
+    A = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+    for l in range(64):
+        for e in range(8):
+            A[l & 31, 8 * (l >> 5) + e] = a_frag[l, e]
+            Bm[8 * (l >> 5) + e, l & 31] = b_frag[l, e]
+    D = A @ Bm
+    out = acc.copy()
+    for l in range(64):
+        for r in range(16):
+            out[l, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return out
+
+
+def test_tiled_index_is_a_bijection_and_lane_linear():
+    R, K = 64, 48
+    idx = np.array([[tiled_index(r, k, K // 16) for k in range(K)] for r in range(R)])
+    assert sorted(idx.ravel().tolist()) == list(range(R * K))
+    plane = np.zeros(R * K)
+    M = np.arange(R * K, dtype=np.float64).reshape(R, K)
+    plane[idx.ravel()] = M.ravel()
+    f = frag_from_tiled(plane, 1, 2, K // 16)
+    for l in range(64):
+        assert np.array_equal(f[l], M[32 + (l & 31), 32 + 8 * (l >> 5): 32 + 8 * (l >> 5) + 8])
+
+
+def test_swapped_gemm_epilogue_addresses():
+    rng = np.random.default_rng(0)
+    N, M, K = 32, 32, 32
+    W, X = rng.standard_normal((N, K)), rng.standard_normal((M, K))
+    wp, xp = np.zeros(N * K), np.zeros(M * K)
+    for r in range(32):
+        for k in range(K):
+            wp[tiled_index(r, k, K // 16)] = W[r, k]
+            xp[tiled_index(r, k, K // 16)] = X[r, k]
+    acc = np.zeros((64, 16))
+    for ks in range(K // 16):
+        acc = mfma_32x32x16(frag_from_tiled(wp, 0, ks, K // 16), frag_from_tiled(xp, 0, ks, K // 16), acc)
+    # epilogue of gemm.h: lane owns token m = lane & 31; reg r is feature 8*(r>>2) + 4*hf + (r&3)
+    out = np.zeros(M * N)
+    for l in range(64):
+        hf, col = l >> 5, l & 31
+        for g in range(4):
+            f = 8 * g + 4 * hf
+            for c in range(4):
+                out[tiled_index(col, f, N // 16) + c] = acc[l, 4 * g + c]
+    Y = X @ W.T
+    for m in range(M):
+        for f in range(N):
+            assert abs(out[tiled_index(m, f, N // 16)] - Y[m, f]) < 1e-9
+
+
+def test_v_key_permutation_matches_softmax_accumulator():
+    """S^T accumulator regs 8jj..8jj+7 of a lane, used verbatim as the PV B-fragment, pair with the V^T
+    fragment written by EpiV: slot (hf, e) <-> key 16*kg + 8*(e>>2) + 4*hf + (e&3)."""
+    rng = np.random.default_rng(1)
+    Lk, D = 32, 32
+    P = rng.standard_normal((32, Lk))          # P[query][key]
+    V = rng.standard_normal((Lk, D))           # V[key][d]
+    # S^T accumulator layout: lane (q = l&31, hf), reg r <-> key (r&3) + 8*(r>>2) + 4*hf
+    sacc = np.zeros((64, 16))
+    for l in range(64):
+        for r in range(16):
+            sacc[l, r] = P[l & 31, (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]
+    # EpiV: [dt][kg][hf][d%32][e], key%16 = 8a + 4b + c -> slot (hfk=b, e=4a+c)
+    vt = np.zeros((Lk // 16, 2, 32, 8))
+    for key in range(Lk):
+        k16 = key & 15
+        a, b, c = k16 >> 3, (k16 >> 2) & 1, k16 & 3
+        vt[key >> 4, b, :, 4 * a + c] = V[key, :]
+    acc = np.zeros((64, 16))
+    for kg in range(Lk // 16):
+        jj = kg & 1
+        pfrag = sacc[:, 8 * jj:8 * jj + 8] if (kg >> 1) == 0 else None
+        vfrag = vt[kg].reshape(64, 8)
+        acc = mfma_32x32x16(vfrag, pfrag, acc)
+    O = P @ V   # [query][d]
+    for l in range(64):
+        for r in range(16):
+            d = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+            assert abs(acc[l, r] - O[l & 31, d]) < 1e-9
+
+
+def test_xcd_remap_is_bijective():
+    def remap(bid, n):
+        q, r = n >> 3, n & 7
+        xcd, idx = bid & 7, bid >> 3
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+    for n in (1, 7, 8, 9, 24, 100, 6144, 6151):
+        assert sorted(remap(b, n) for b in range(n)) == list(range(n))

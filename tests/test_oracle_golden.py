@@ -1,0 +1,87 @@
+"""Pins the CPU oracle to the golden vectors the REFERENCE produced (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from egoego_release_amd import ModelConfig, make_weights, make_head_windows
+from oracle import egoego_oracle as O
+
+TOL = 0.0  # same torch build, same aten ops -> bit-identical; relaxed automatically if the build differs
+
+
+def _close(a, b, tol=2e-6):
+    d = np.abs(a - b).max()
+    assert d <= tol, d
+
+
+def test_schedule_matches_reference(golden):
+    s = O.make_schedule(1000, "cosine")
+    for k, v in s.items():
+        assert np.array_equal(v.numpy(), golden["sched_" + k]), k
+    assert np.array_equal(O.make_schedule(1000, "linear")["betas"].numpy(), golden["sched_linear_betas"])
+    # known answers quoted in SURVEY.md Appendix A.0
+    assert s["posterior_mean_coef1"][0] == 1.0 and s["posterior_mean_coef2"][0] == 0.0
+    assert abs(s["posterior_log_variance_clipped"][0].item() + 46.0517) < 1e-3
+    with pytest.raises(ValueError):
+        O.make_schedule(10, "sigmoid")
+
+
+@pytest.mark.parametrize("T,tags", [(120, ("t0", "t500", "t999", "tmix")), (30, ("t0", "tmix")), (196, ("t0", "tmix"))])
+def test_denoise_matches_reference(golden, T, tags):
+    cfg = ModelConfig(max_timesteps=T + 1)
+    sd = make_weights(cfg, 0)
+    g = torch.Generator().manual_seed(int(golden[f"denoise_T{T}_seed"]))
+    x_all = torch.randn(2, T, 396, generator=g)
+    tt = {"t0": [0, 0], "t500": [500, 500], "t999": [999, 999], "tmix": [3, 977]}
+    with torch.no_grad():
+        for tag in tags:
+            y = O.denoise(sd, x_all, torch.tensor(tt[tag]))
+            _close(y.numpy(), golden[f"denoise_T{T}_{tag}"])
+
+
+def test_denoise_padding_mask(golden):
+    cfg = ModelConfig()
+    sd = make_weights(cfg, 0)
+    x_all = torch.randn(2, 120, 396, generator=torch.Generator().manual_seed(77))
+    pm = torch.ones(2, 1, 121).bool()
+    pm[0, 0, 100:] = False
+    pm[1, 0, 61:] = False
+    with torch.no_grad():
+        y = O.denoise(sd, x_all, torch.tensor([10, 700]), padding_mask=pm)
+    _close(y.numpy(), golden["denoise_padmask"])
+
+
+@pytest.mark.parametrize("objective", ["pred_x0", "pred_noise"])
+def test_p_sample_matches_reference(golden, objective):
+    cfg = ModelConfig(objective=objective)
+    sd = make_weights(cfg, 0)
+    sched = O.make_schedule(1000)
+    g = torch.Generator().manual_seed(2024)
+    x = torch.randn(2, 120, 198, generator=g)
+    xc = torch.randn(2, 120, 198, generator=g)
+    with torch.no_grad():
+        for tval in (500, 0):
+            noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(555))
+            y = O.p_sample(sd, sched, x, torch.full((2,), tval), xc, noise, objective)
+            _close(y.numpy(), golden[f"p_sample_{objective}_t{tval}"], 4e-6)
+    with pytest.raises(ValueError):
+        O.p_sample(sd, sched, x, torch.full((2,), 1), xc, x, "pred_v")
+
+
+@pytest.mark.parametrize("tag,B,S", [("b1_s10", 1, 10), ("b2_s50", 2, 50), ("b1_s1000", 1, 1000)])
+def test_sample_chain_matches_reference(golden, tag, B, S):
+    cfg = ModelConfig()
+    sd = make_weights(cfg, 0)
+    sched = O.make_schedule(1000)
+    xs, cm = make_head_windows(B, 120, seed=11)
+    with torch.no_grad():
+        y = O.p_sample_loop(sd, sched, xs, cm, torch.Generator().manual_seed(123), num_timesteps=S)
+    # the chain is chaotic: allow round-off growth if this torch build is not the authoring one
+    _close(y.numpy(), golden[f"sample_{tag}"], 1e-4)
+    assert np.abs(y.numpy()).max() <= 1.0  # final step returns clamp(x0) (c1[0]=1, c2[0]=0)
+
+
+def test_head_condition_mask():
+    m = O.head_condition_mask((2, 5, 198))
+    assert m.sum().item() == 2 * 5 * (198 - 9)
+    assert m[..., 45:48].sum() == 0 and m[..., 156:162].sum() == 0
