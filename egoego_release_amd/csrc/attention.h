@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) qb[(ph + 1) & 1][ks][p] = *q_src(ph + 1, ks, p);
         }
+        __builtin_amdgcn_sched_barrier(0);  // loads stay above the MFMAs (hipcc would sink them to their use)
         const char* sb = smem + (size_t)buf * STAGE_BYTES + lane * 16;
         if constexpr (ph < 4) {
             // S^T += K_chunk x Q_chunk^T
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                     }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph < 7) {
             char* dst = smem + (size_t)(buf ^ 1) * STAGE_BYTES + ((size_t)wave * 64 + lane) * 16;
 #pragma unroll

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -57,6 +58,9 @@ struct egoego_ctx {
 };
 
 static const int N_MODEL = 512;
+static int g_stagger = getenv("EGOEGO_STAGGER") ? atoi(getenv("EGOEGO_STAGGER")) : 0;           // perf experiment
+static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debug_trace_buffer
+static int g_ablate = getenv("EGOEGO_ABLATE") ? atoi(getenv("EGOEGO_ABLATE")) : 0;  // perf-debug only
 
 struct Geometry {
     int B, T, L, KT, Lp, Mp, Mvalid;
@@ -75,7 +79,7 @@ static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g) {
     else return fail(EGOEGO_E_INVALID, "window length T=%d not supported (T+1 must be <= 224)", T);
     g.Lp = 32 * g.KT;
     g.Mvalid = B * g.Lp;
-    g.Mp = (int)align_up((size_t)g.Mvalid, 128);
+    g.Mp = (int)align_up((size_t)g.Mvalid, 256);
     return 0;
 }
 
@@ -139,14 +143,18 @@ static hipError_t allow_smem(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-// GEMM tile configurations (features x tokens per block):
-//   A: 128 x 128, 4 waves (2x2), wave tile 64 x 64, 2 k-steps per stage   — embed, QKV, FFN-1
-//   B: 512 x  64, 4 waves (4x1), wave tile 128 x 64, 1 k-step per stage   — fc / FFN-2 + residual + LayerNorm
-//   C: 256 x  64, 4 waves (4x1), wave tile 64 x 64, 2 k-steps per stage   — linear_out + DDPM posterior
-template <int NP> using CfgA = GemmCfg<2, 2, 2, 2, 2, NP, false>;
-template <int NP> using CfgAV = GemmCfg<2, 2, 2, 2, 2, NP, true>;
-template <int NP> using CfgB = GemmCfg<4, 2, 4, 1, (NP == 2 ? 1 : 2), NP, false>;
-template <int NP> using CfgC = GemmCfg<2, 2, 4, 1, 2, NP, false>;
+// GEMM tile configurations (features x tokens per block), chosen by measurement on MI355X
+// (tools/kernel_times.py, tools/block_trace.py, EGOEGO_ABLATE):
+//   A: 256 x 128, 4 waves 2(f) x 2(t), 3-stage LDS ring (72 KiB), two workgroups per CU so one block's
+//      store-heavy epilogue overlaps the other's main loop              — embed, QKV, FFN-1
+//   B: 512 x 128, 8 waves 4(f) x 2(t), 3-stage ring (120 KiB)            — fc / FFN-2 + residual + LayerNorm
+//   C: 256 x 128, 8 waves of 64f x 64t, 2-stage ring                      — linear_out + DDPM tail
+// Every wave owns a 128f x 64t (C: 64f x 64t) accumulator tile.
+template <int NP> using CfgA = GemmCfg<4, 2, 2, 2, 1, NP, false, 2, 3>;
+template <int NP> using CfgAV = GemmCfg<4, 2, 2, 2, 1, NP, true, 2, 3>;
+template <int NP> using CfgB = GemmCfg<4, 2, 4, 2, (NP == 2 ? 1 : 2), NP, false, 1, 3>;
+template <int NP> using CfgC = GemmCfg<2, 2, 4, 2, 2, NP, false>;
+static const int BLK_A_F = 256, BLK_A_T = 128, BLK_B_T = 128;
 
 template <class C, class Epi>
 static int launch_gemm(const GemmOperands& g, const Epi& epi, hipStream_t s) {
@@ -200,7 +208,7 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
-        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / 128, Mp / 128};
+        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, Mp / BLK_A_T, g_ablate, g_stagger, g_trace};
         EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B};
         if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
     }
@@ -211,7 +219,7 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
         // --- Q, K, V projections (TM:71-73)
         {
             ProfScope ps(c, EGOEGO_K_QKV, s);
-            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / 128, Mp / 128};
+            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, Mp / BLK_A_T, g_ablate, g_stagger, g_trace};
             EpiQK<NP> eqk{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
             EpiV<NP> ev{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
             auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
@@ -220,7 +228,7 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
                 HIP_TRY(allow_smem(kern, CfgA<NP>::SMEM_BYTES));
                 once = true;
             }
-            kern<<<dim3(go.nfb * go.ntb), dim3(256), CfgA<NP>::SMEM_BYTES, s>>>(go, eqk, ev, 2 * HD / 128);
+            kern<<<dim3(go.nfb * go.ntb), dim3(CfgA<NP>::NT), CfgA<NP>::SMEM_BYTES, s>>>(go, eqk, ev, 2 * HD / BLK_A_F);
             HIP_TRY(hipGetLastError());
         }
         if (last_dbg && (io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V))
@@ -235,15 +243,15 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
         // --- fc + residual + LayerNorm (+ padding mask) (TM:92-93, 135)
         {
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
-            GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, Mp / 64};
-            EpiResLN<NP, 4, 64> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+            GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, Mp / BLK_B_T, g_ablate, g_stagger, g_trace};
+            EpiResLN<NP, 4, 128> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
             if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_LN) return 0;
         // --- FFN conv 1 + ReLU (TM:111)
         {
             ProfScope ps(c, EGOEGO_K_FFN1, s);
-            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / 128, Mp / 128};
+            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, Mp / BLK_A_T, g_ablate, g_stagger, g_trace};
             EpiTiled<true, NP> e{L.b_1, w.F, w.h_plane, N_MODEL / 16};
             if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
         }
@@ -251,15 +259,15 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
         // --- FFN conv 2 + residual + LayerNorm (+ padding mask) (TM:111-114, 139)
         {
             ProfScope ps(c, EGOEGO_K_FFN2_LN, s);
-            GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, Mp / 64};
-            EpiResLN<NP, 4, 64> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
+            GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, Mp / BLK_B_T, g_ablate, g_stagger, g_trace};
+            EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
             if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_LAYER_OUT) return 0;
     }
     if (io.run_out) {
         ProfScope ps(c, EGOEGO_K_OUT, s);
-        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, Mp / 64};
+        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, Mp / CfgC<NP>::BT, g_ablate, g_stagger, g_trace};
         EpiOut<NP> e{io.out};
         if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
     }
@@ -615,6 +623,13 @@ int egoego_rot6d_to_matrix(const float* d_in, float* d_out, int64_t n, void* str
     const int64_t blocks = (n + 255) / 256;
     k_rot6d_to_matrix<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, (hipStream_t)stream>>>(d_in, d_out, n);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* perf-debug only (not in the public header): per-block timestamps of every GEMM launch go to `buf`
+ * ([grid][4] u64, overwritten by each launch); nullptr disables. */
+int egoego_debug_trace_buffer(unsigned long long* buf) {
+    g_trace = buf;
     return 0;
 }
 

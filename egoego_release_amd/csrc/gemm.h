@@ -28,6 +28,9 @@ struct GemmOperands {
     int K16;  // K / 16
     int nfb;  // feature blocks in the grid
     int ntb;  // token blocks in the grid
+    int ablate;  // perf-debug only (EGOEGO_ABLATE): 1 = skip global->LDS loads, 2 = skip the epilogue
+    int stagger;  // perf experiment (EGOEGO_STAGGER): second-slot workgroups start this many microseconds late
+    unsigned long long* trace;  // perf-debug: [nblocks][4] = {t_start, t_mainloop_end, t_end, hw_id | xcc_id << 32} or nullptr
 };
 
 // Blocks that share an activation tile (same token block, different feature blocks) are made
@@ -39,8 +42,25 @@ EG_D int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int FT_, int TT_, int NWF_, int NWT_, int KS_, int NP_, bool ACT_ROWS_>
+// Block-id -> (feature block, token block).  After xcd_remap every XCD owns a contiguous range of ids;
+// inside it, ids walk groups of 8 token blocks x all feature blocks (token fastest), so the ~32 blocks
+// resident on an XCD at any time form an 8-token-block x 4-feature-block patch whose operand tiles are
+// shared through that XCD's L2 while the blocks stream K in near lockstep.
+EG_D void grouped_map(int lid, int nfb, int ntb, int& fblk, int& tblk) {
+    constexpr int GT = 8;
+    const int per_group = GT * nfb;
+    const int grp = lid / per_group;
+    const int first_t = grp * GT;
+    const int gsz = min(GT, ntb - first_t);
+    const int r = lid - grp * per_group;
+    tblk = first_t + r % gsz;
+    fblk = r / gsz;
+}
+
+template <int FT_, int TT_, int NWF_, int NWT_, int KS_, int NP_, bool ACT_ROWS_, int MINW_ = 1, int NSTAGE_ = 2>
 struct GemmCfg {
+    static constexpr int MINW = MINW_;      // min waves per SIMD the register allocation must allow
+    static constexpr int NSTAGE = NSTAGE_;  // LDS ring depth; NSTAGE-1 stages are in flight (LDS-DMA) during the MFMAs
     static constexpr int FT = FT_, TT = TT_, NWF = NWF_, NWT = NWT_, KS = KS_, NP = NP_;
     static constexpr bool ACT_ROWS = ACT_ROWS_;
     static constexpr int NW = NWF * NWT, NT = NW * 64;
@@ -50,8 +70,9 @@ struct GemmCfg {
     static constexpr int NBLK = (WT + AT) * NP * KS;  // 1 KiB fragment blocks per stage
     static constexpr int NCH = NBLK / NW;             // 16-byte chunks per thread per stage
     static constexpr int STAGE_BYTES = NBLK * 1024;
-    static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+    static constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;
     static_assert(NBLK % NW == 0, "stage blocks must divide evenly over the waves");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4 && 2 * NCH < 64, "ring depth / vmcnt range");
 };
 
 template <class C, class Epi>
@@ -62,6 +83,12 @@ struct GemmBody {
         const int wave = wave_id_uniform();
         const int lane = threadIdx.x & 63;
         const int wf = wave % C::NWF, wt = wave / C::NWF;
+        if (g.trace && threadIdx.x == 0) {
+            g.trace[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
+            g.trace[65536 + (size_t)blockIdx.x * 2] = __builtin_readcyclecounter();
+            g.trace[(size_t)blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                  ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        }
 
         // Per-thread source pointers of this stage's chunks (wave-uniform base + lane).
         const u32x4* gp[NCH];
@@ -90,84 +117,192 @@ struct GemmBody {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         const int ns = g.K16 / KS;
-        auto compute = [&](int buf) {
-            const char* sb = smem + (size_t)buf * C::STAGE_BYTES + lane * 16;
+        // ---- software pipeline -------------------------------------------------------------------
+        // Ring of NS LDS stages filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight
+        // into the fragment-tiled image at wave-uniform base + 16*lane; no VGPR staging, no ds_write).
+        // Iteration s:  counted vmcnt (my share of stage s landed) -> raw s_barrier (everyone's landed,
+        // everyone finished reading stage s-1) -> ds_read fragments of stage s into register set s&1
+        // -> MFMAs of stage s-1 from the OTHER register set, with the DMA instructions of stage s+D
+        // dropped between them.  So the matrix pipe has work the moment the barrier opens, LDS read
+        // latency and DMA issue cost sit in the MFMA shadow, and D = NS-1 stages stay in flight.
+        // (__syncthreads() is avoided on purpose: with a DMA in flight it would drain vmcnt to 0.)
+        constexpr int NS = C::NSTAGE, D = NS - 1;
+        constexpr int FH = FT / 2;  // feature tiles per half
+        static_assert(FT % 2 == 0, "the pipeline alternates two halves of the wave's feature tiles");
+        struct ActFr { bf16x8 h[TT], l[TT]; };
+        struct WFr { bf16x8 h[FH], l[FH]; };
+        auto read_act = [&](int slot, int ks, ActFr& f) {
+            const char* sb = smem + (size_t)slot * C::STAGE_BYTES + lane * 16;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 wh[FT], wl[FT], ah[TT], al[TT];
-#pragma unroll
-                for (int i = 0; i < FT; ++i) {
-                    wh[i] = *(const bf16x8*)(sb + ((0 * WT + wf * FT + i) * KS + ks) * 1024);
-                    if (NP == 2) wl[i] = *(const bf16x8*)(sb + ((1 * WT + wf * FT + i) * KS + ks) * 1024);
-                }
-#pragma unroll
-                for (int j = 0; j < TT; ++j) {
-                    ah[j] = *(const bf16x8*)(sb + ((WT * NP + 0 * AT + wt * TT + j) * KS + ks) * 1024);
-                    if (NP == 2) al[j] = *(const bf16x8*)(sb + ((WT * NP + 1 * AT + wt * TT + j) * KS + ks) * 1024);
-                }
-#pragma unroll
-                for (int i = 0; i < FT; ++i)
-#pragma unroll
-                    for (int j = 0; j < TT; ++j) {
-                        if (C::ACT_ROWS) {
-                            if (NP == 2) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], wh[i], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], wl[i], acc[i][j], 0, 0, 0);
-                            }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], wh[i], acc[i][j], 0, 0, 0);
-                        } else {
-                            if (NP == 2) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], ah[j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], al[j], acc[i][j], 0, 0, 0);
-                            }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], ah[j], acc[i][j], 0, 0, 0);
-                        }
-                    }
+            for (int j = 0; j < TT; ++j) {
+                f.h[j] = *(const bf16x8*)(sb + ((WT * NP + 0 * AT + wt * TT + j) * KS + ks) * 1024);
+                if (NP == 2) f.l[j] = *(const bf16x8*)(sb + ((WT * NP + 1 * AT + wt * TT + j) * KS + ks) * 1024);
             }
         };
-        {
-            u32x4 st[NCH];
+        auto read_w = [&](int slot, int ks, int half, WFr& f) {
+            const char* sb = smem + (size_t)slot * C::STAGE_BYTES + lane * 16;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) st[j] = gp[j][0];
-            char* dst = smem + ((size_t)wave * 64 + lane) * 16;
+            for (int i = 0; i < FH; ++i) {
+                f.h[i] = *(const bf16x8*)(sb + ((0 * WT + wf * FT + half * FH + i) * KS + ks) * 1024);
+                if (NP == 2) f.l[i] = *(const bf16x8*)(sb + ((1 * WT + wf * FT + half * FH + i) * KS + ks) * 1024);
+            }
+        };
+        auto issue_one = [&](int stage, int slot, int j) {
+            char* dst = smem + (size_t)slot * C::STAGE_BYTES + (size_t)wave * 1024;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(gp[j] + (size_t)stage * KS * 64),
+                (__attribute__((address_space(3))) void*)(dst + (size_t)j * NW * 1024), 16, 0, 0);
+        };
+        // MFMAs of one half (FH x TT accumulator triples).  DMA instruction q of (stage, slot) is issued
+        // after triple q - q0, so the DMA issue cost is paid in the shadow of the matrix pipe.
+        auto mfmas = [&](const ActFr& a, const WFr& w, int half, bool dma, int stage, int slot, int q0) {
+            constexpr int NTRI = FH * TT;
+            constexpr int PER = (NCH + 2 * NTRI - 1) / (2 * NTRI);
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * NW * 1024) = st[j];
+            for (int i = 0; i < FH; ++i)
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    f32x16& c = acc[half * FH + i][j];
+                    if (C::ACT_ROWS) {
+                        if (NP == 2) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[j], w.h[i], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[j], w.l[i], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[j], w.h[i], c, 0, 0, 0);
+                    } else {
+                        if (NP == 2) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l[i], a.h[j], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[i], a.l[j], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[i], a.h[j], c, 0, 0, 0);
+                    }
+                    const int n = i * TT + j;
+#pragma unroll
+                    for (int q = 0; q < PER; ++q)
+                        if (q0 + n * PER + q < NCH && dma) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_one(stage, slot, q0 + n * PER + q);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+        };
+        constexpr int DMA_PER_HALF = ((NCH + 2 * FH * TT - 1) / (2 * FH * TT)) * FH * TT;
+        const bool loads_on = !(g.ablate & 1);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < ns && loads_on) {
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) issue_one(d, d, j);
+            }
+        auto wait_stage = [&](int st) {  // stages st+1 .. min(st+D-1, ns-1) may stay in flight
+            const int ahead = min(D - 1, ns - 1 - st);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of the slot about to be refilled are done
+            __builtin_amdgcn_s_barrier();
+        };
+        // ---- software pipeline over k-steps kk = stage*KS + ks ------------------------------------
+        // iteration kk:  [new stage: counted vmcnt + barrier]  read act(kk), W-half0(kk)
+        //                MFMA half1(kk-1)  (+ the DMA instructions refilling the slot of the previous stage)
+        //                read W-half1(kk)
+        //                MFMA half0(kk)
+        // Every batch of ds_reads is followed by 3*FH*TT MFMAs on operands that are ALREADY in registers,
+        // so the matrix pipe has work the moment the barrier opens and LDS latency stays in its shadow.
+        ActFr a0, a1;
+        WFr w0, w1;
+        const int nu = ns * KS;
+        int slot = 0;   // slot of the stage being read
+        int pslot = 0;  // slot of the previous stage (the one being refilled)
+        wait_stage(0);
+        if (D < ns && loads_on) {  // stage D goes into the one slot the prologue left empty
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) issue_one(D, D, j);
         }
-        __syncthreads();
-        // steady state: stage s+1 travels global -> registers while stage s feeds the MFMAs
-        for (int s = 0; s + 1 < ns; ++s) {
-            const int buf = s & 1;
-            u32x4 st[NCH];
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) st[j] = gp[j][(size_t)(s + 1) * KS * 64];
-            compute(buf);
-            char* dst = smem + (size_t)(buf ^ 1) * C::STAGE_BYTES + ((size_t)wave * 64 + lane) * 16;
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * NW * 1024) = st[j];
-            __syncthreads();
+        read_act(0, 0, a0);
+        read_w(0, 0, 0, w0);
+        read_w(0, 0, 1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a0, w0, 0, false, 0, 0, 0);
+        auto unit = [&](int kk, ActFr& acur, const ActFr& aprev) {
+            const int st = kk / KS, ks = kk - st * KS;
+            bool dma = false;
+            if (ks == 0) {
+                wait_stage(st);
+                pslot = slot;
+                if (++slot == NS) slot = 0;
+                dma = (st - 1 + NS < ns) && loads_on;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_act(slot, ks, acur);
+            read_w(slot, ks, 0, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(aprev, w1, 1, dma, st - 1 + NS, pslot, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_w(slot, ks, 1, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(acur, w0, 0, dma, st - 1 + NS, pslot, DMA_PER_HALF);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kk = 1;
+        for (; kk + 1 < nu; kk += 2) {
+            unit(kk, a1, a0);
+            unit(kk + 1, a0, a1);
         }
-        compute((ns - 1) & 1);
+        if (kk < nu) {
+            unit(kk, a1, a0);
+            mfmas(a1, w1, 1, false, 0, 0, 0);
+        } else {
+            mfmas(a0, w1, 1, false, 0, 0, 0);
+        }
         __syncthreads();
 
         const int f0 = (fblk * WT + wf * FT) * 32;
         const int t0 = (tblk * AT + wt * TT) * 32;
+        if (g.trace && threadIdx.x == 0) {
+            g.trace[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
+            g.trace[65536 + (size_t)blockIdx.x * 2 + 1] = __builtin_readcyclecounter();
+        }
+        if (g.ablate & 2) {
+            if (acc[0][0][0] == 123.456f) *(float*)smem = acc[FT - 1][TT - 1][7];  // keep the MFMAs alive
+            return;
+        }
         epi.template run<FT, TT>(acc, f0, t0, lane, wf, wt, smem);
+        if (g.trace) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) g.trace[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
+        }
     }
 };
 
+// Perf experiment: the first 256 blocks of a grid take the first slot of every CU, the next 256 the
+// second; delaying the second group de-phases the two co-resident workgroups so that one's epilogue
+// (HBM writes) overlaps the other's MFMA main loop.
+EG_D void stagger_start(int us) {
+    if (us > 0 && ((blockIdx.x >> 8) & 1)) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (long long)us * 100) __builtin_amdgcn_s_sleep(32);  // 100 MHz constant clock
+    }
+}
+
 template <class C, class Epi>
-__global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands g, Epi epi) {
+__global__ __launch_bounds__(C::NT, C::MINW) void gemm_kernel(GemmOperands g, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    stagger_start(g.stagger);
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    GemmBody<C, Epi>::run(g, epi, lid % g.nfb, lid / g.nfb, smem);
+    int fblk, tblk;
+    grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
+    GemmBody<C, Epi>::run(g, epi, fblk, tblk, smem);
 }
 
 // Q/K feature blocks run swapped, V feature blocks un-swapped; the branch is block-uniform.
 template <class CQK, class EpiQK, class CV, class EpiV>
-__global__ __launch_bounds__(CQK::NT) void qkv_kernel(GemmOperands g, EpiQK eqk, EpiV ev, int n_qk_fblocks) {
+__global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_kernel(GemmOperands g, EpiQK eqk, EpiV ev, int n_qk_fblocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    stagger_start(g.stagger);
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int fblk = lid % g.nfb, tblk = lid / g.nfb;
+    int fblk, tblk;
+    grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
     if (fblk < n_qk_fblocks)
         GemmBody<CQK, EpiQK>::run(g, eqk, fblk, tblk, smem);
     else

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-kernel mean launch time (HIP events inside the library) for one configuration."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from egoego_release_amd import ModelConfig, make_weights, _lib
+from egoego_release_amd.model import CondGaussianDiffusion
+
+B, T = int(os.environ.get("KT_B", 256)), int(os.environ.get("KT_T", 120))
+prec = int(os.environ.get("KT_PREC", 3))
+cfg = ModelConfig(max_timesteps=T + 1)
+m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+m.load_state_dict(make_weights(cfg, 0), strict=False)
+m.hip_precision = prec
+m = m.cuda()
+eng = m.hip_engine()
+x = torch.randn(B, T, 198, device="cuda")
+xc = torch.randn(B, T, 198, device="cuda")
+eng.sample_loop_(x, xc, 999, 3, noise_mode=_lib.NOISE_PHILOX)
+torch.cuda.synchronize()
+tot = 0.0
+for k in ("embed", "qkv", "attn", "fc_ln", "ffn1", "ffn2_ln", "out"):
+    eng.profile_begin(k)
+    eng.sample_loop_(x, xc, 900, 5, noise_mode=_lib.NOISE_PHILOX)
+    us, n = eng.profile_end()
+    per_step = us * n / 5
+    tot += per_step
+    print(f"{k:8s} {us:9.1f} us x {n // 5}/step = {per_step:9.1f} us/step")
+print(f"sum      {tot:9.1f} us/step")
