@@ -30,10 +30,11 @@ struct AttnArgs {
     int HD16;  // H*256/16
     int H;
     int L;     // valid keys (T + 1); keys >= L are padding and get probability 0
+    int bh0;   // first (batch, head) pair of this launch (window-chunked launches)
 };
 
 template <int KT, int NP>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (KT <= 4 ? 2 : 1)) void attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NCH = KT * NP;                  // 16-byte chunks per thread per phase
     constexpr int STAGE_BYTES = KT * NP * 4096;   // K chunk: KT tiles x NP planes x 4 k-steps x 1 KiB
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63;
     const int hf = lane >> 5, col = lane & 31;
-    const int bh = blockIdx.y;
+    const int bh = blockIdx.y + a.bh0;
     const int qt_raw = blockIdx.x * 4 + wave;
     const bool active = qt_raw < KT;
     const int qt = active ? qt_raw : KT - 1;
@@ -71,28 +72,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     bf16x8 phi[KT][2], plo[KT][2];
 
     u32x4 qb[2][4][NP];  // Q fragments of the current / next d_k chunk (static ping-pong)
-    {
-        u32x4 st[NCH];
+    // K / V^T chunks travel global -> LDS by LDS-DMA (16 B per lane at wave-uniform base + 16*lane: the
+    // fragment image itself), one phase ahead of the MFMAs; two slots, so two workgroups fit per CU.
+    auto dma_phase = [&](int ph, int slot) {
+        char* dst = smem + (size_t)slot * STAGE_BYTES + (size_t)wave * 1024;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) st[j] = *stage_src(0, j);
+        for (int j = 0; j < NCH; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)stage_src(ph, j),
+                                             (__attribute__((address_space(3))) void*)(dst + (size_t)j * 4096), 16, 0, 0);
+    };
+    dma_phase(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) qb[0][ks][p] = *q_src(0, ks, p);
-        char* dst = smem + ((size_t)wave * 64 + lane) * 16;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * 4096) = st[j];
-    }
-    __syncthreads();
+        for (int p = 0; p < NP; ++p) qb[0][ks][p] = *q_src(0, ks, p);
 
     auto phase = [&](auto PHC) {
         constexpr int ph = decltype(PHC)::value;
         constexpr int buf = ph & 1;
-        u32x4 st[NCH];
-        if constexpr (ph < 7) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) st[j] = *stage_src(ph + 1, j);
-        }
+        // my share of this phase's chunk has landed; after the barrier everyone's has, and everyone is
+        // done reading the other slot, which the next DMA may now overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (ph < 7) dma_phase(ph + 1, buf ^ 1);
         if constexpr (ph < 3) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -191,13 +194,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                     }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ph < 7) {
-            char* dst = smem + (size_t)(buf ^ 1) * STAGE_BYTES + ((size_t)wave * 64 + lane) * 16;
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) *(u32x4*)(dst + (size_t)j * 4096) = st[j];
-        }
-        __syncthreads();
     };
     phase(std::integral_constant<int, 0>{});
     phase(std::integral_constant<int, 1>{});

@@ -60,6 +60,7 @@ struct egoego_ctx {
 static const int N_MODEL = 512;
 static int g_stagger = getenv("EGOEGO_STAGGER") ? atoi(getenv("EGOEGO_STAGGER")) : 0;           // perf experiment
 static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debug_trace_buffer
+static int g_chunk = getenv("EGOEGO_CHUNK") ? atoi(getenv("EGOEGO_CHUNK")) : 0;  // windows per denoiser pass (0 = whole batch)
 static int g_ablate = getenv("EGOEGO_ABLATE") ? atoi(getenv("EGOEGO_ABLATE")) : 0;  // perf-debug only
 
 struct Geometry {
@@ -202,13 +203,21 @@ struct StepIO {
     OutParams out;
 };
 
+// One denoiser pass over windows [w0, w0 + nw).  Token rows of a chunk are contiguous, so a chunk is just
+// a token-block offset for the GEMMs and a (batch, head) offset for attention.
 template <int NP>
-static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s) {
-    const int Mp = g.Mp, H = c->H, HD = c->HD;
+static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s, int w0,
+                        int nw) {
+    const int H = c->H, HD = c->HD;
+    const int row0 = w0 * g.Lp;
+    int rows = nw * g.Lp;
+    if (w0 + nw >= g.B) rows = g.Mp - row0;  // the last chunk also carries the rows that pad Mp to the block size
+    const int tb_a = rows / BLK_A_T, tb_b = rows / BLK_B_T, tb_c = rows / CfgC<NP>::BT;
+    const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
-        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, Mp / BLK_A_T, g_ablate, g_stagger, g_trace};
+        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
         EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B};
         if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
     }
@@ -219,7 +228,7 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
         // --- Q, K, V projections (TM:71-73)
         {
             ProfScope ps(c, EGOEGO_K_QKV, s);
-            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, Mp / BLK_A_T, g_ablate, g_stagger, g_trace};
+            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
             EpiQK<NP> eqk{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
             EpiV<NP> ev{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
             auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
@@ -232,18 +241,18 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
             HIP_TRY(hipGetLastError());
         }
         if (last_dbg && (io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V))
-            return 0;
+            continue;
         // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
         {
             ProfScope ps(c, EGOEGO_K_ATTN, s);
-            AttnArgs a{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L};
-            if (int r = launch_attn<NP>(a, g.KT, g.B * H, s)) return r;
+            AttnArgs a{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L, w0 * H};
+            if (int r = launch_attn<NP>(a, g.KT, nw * H, s)) return r;
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_OUT) return 0;
         // --- fc + residual + LayerNorm (+ padding mask) (TM:92-93, 135)
         {
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
-            GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, Mp / BLK_B_T, g_ablate, g_stagger, g_trace};
+            GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
             EpiResLN<NP, 4, 128> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
             if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
         }
@@ -251,7 +260,7 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
         // --- FFN conv 1 + ReLU (TM:111)
         {
             ProfScope ps(c, EGOEGO_K_FFN1, s);
-            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, Mp / BLK_A_T, g_ablate, g_stagger, g_trace};
+            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
             EpiTiled<true, NP> e{L.b_1, w.F, w.h_plane, N_MODEL / 16};
             if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
         }
@@ -259,7 +268,7 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
         // --- FFN conv 2 + residual + LayerNorm (+ padding mask) (TM:111-114, 139)
         {
             ProfScope ps(c, EGOEGO_K_FFN2_LN, s);
-            GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, Mp / BLK_B_T, g_ablate, g_stagger, g_trace};
+            GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
             EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
             if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
         }
@@ -267,9 +276,24 @@ static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w,
     }
     if (io.run_out) {
         ProfScope ps(c, EGOEGO_K_OUT, s);
-        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, Mp / CfgC<NP>::BT, g_ablate, g_stagger, g_trace};
+        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c, g_ablate, g_stagger, g_trace};
         EpiOut<NP> e{io.out};
         if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
+    }
+    return 0;
+}
+
+// The batch is walked in chunks of windows, each chunk going through the WHOLE denoiser before the next
+// one starts: a chunk's intermediates (Q/K/V alone are 1.6 MB per window per layer) then stay in the
+// 256 MiB Infinity Cache between the kernel that writes them and the kernel that reads them.
+template <int NP>
+static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s) {
+    int chunk = g_chunk > 0 ? g_chunk : g.B;
+    const int per = 256 / g.Lp > 0 ? 256 / g.Lp : 1;  // windows per 256-row block
+    chunk = (chunk + per - 1) / per * per;
+    for (int w0 = 0; w0 < g.B; w0 += chunk) {
+        const int nw = (w0 + chunk < g.B) ? chunk : g.B - w0;
+        if (int r = run_chunk_np<NP>(c, g, w, io, s, w0, nw)) return r;
     }
     return 0;
 }

@@ -28,6 +28,7 @@ struct GemmOperands {
     int K16;  // K / 16
     int nfb;  // feature blocks in the grid
     int ntb;  // token blocks in the grid
+    int tblk0;  // first token block of this launch (window-chunked launches)
     int ablate;  // perf-debug only (EGOEGO_ABLATE): 1 = skip global->LDS loads, 2 = skip the epilogue
     int stagger;  // perf experiment (EGOEGO_STAGGER): second-slot workgroups start this many microseconds late
     unsigned long long* trace;  // perf-debug: [nblocks][4] = {t_start, t_mainloop_end, t_end, hw_id | xcc_id << 32} or nullptr
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_kernel(GemmOperands g, Ep
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int fblk, tblk;
     grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
-    GemmBody<C, Epi>::run(g, epi, fblk, tblk, smem);
+    GemmBody<C, Epi>::run(g, epi, fblk, tblk + g.tblk0, smem);
 }
 
 // Q/K feature blocks run swapped, V feature blocks un-swapped; the branch is block-uniform.
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_kernel(GemmOperands g,
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int fblk, tblk;
     grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
+    tblk += g.tblk0;
     if (fblk < n_qk_fblocks)
         GemmBody<CQK, EpiQK>::run(g, eqk, fblk, tblk, smem);
     else
@@ -455,18 +457,23 @@ struct EpiResLN {
     __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem) const {
         static_assert(NWF * FT * 32 == 512, "LayerNorm epilogue needs the whole 512-wide row in the block");
         const int hf = lane >> 5, col = lane & 31;
-        float* red1 = (float*)smem;        // [NWF][BT]
-        float* red2 = red1 + NWF * BT;     // [NWF][BT]
-        // y = acc + bias + residual
+        float* red1 = (float*)smem;     // [TT][NWF][BT]  per-wave partial sums
+        float* red2 = red1 + TT * NWF * BT;
+        // A token is one lane (col) of one token tile j, so LayerNorm is independent per j: the tiles are
+        // processed one after the other (fenced) to keep the live register set small — doing both at once
+        // spills.
 #pragma unroll
-        for (int i = 0; i < FT; ++i)
+        for (int j = 0; j < TT; ++j) {
+            const int m = t0 + j * 32 + col;
+            const int slot = (j * NWF) * BT + (wt * TT + j) * 32 + col;
+            // y = acc + bias + residual
+            float s1 = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = f0 + i * 32 + 8 * g + 4 * hf;
-                const float4 b = *(const float4*)(bias + f);
+            for (int i = 0; i < FT; ++i)
 #pragma unroll
-                for (int j = 0; j < TT; ++j) {
-                    const int m = t0 + j * 32 + col;
+                for (int g = 0; g < 4; ++g) {
+                    const int f = f0 + i * 32 + 8 * g + 4 * hf;
+                    const float4 b = *(const float4*)(bias + f);
                     const size_t idx = tiled_index(m, f, 32);
                     float r[4];
                     const uint2 rh = *(const uint2*)(res + idx);
@@ -480,77 +487,52 @@ struct EpiResLN {
                     acc[i][j][4 * g + 1] += b.y + r[1];
                     acc[i][j][4 * g + 2] += b.z + r[2];
                     acc[i][j][4 * g + 3] += b.w + r[3];
+                    s1 += (acc[i][j][4 * g + 0] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
                 }
-            }
-        // mean over the 512 features of each token
-        float mean[TT], rstd[TT];
+            s1 += __shfl_xor(s1, 32);
+            if (hf == 0) red1[slot + wf * BT] = s1;
+            __syncthreads();
+            float mean = 0.f;
 #pragma unroll
-        for (int j = 0; j < TT; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < FT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-            s += __shfl_xor(s, 32);
-            if (hf == 0) red1[wf * BT + (wt * TT + j) * 32 + col] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TT; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWF; ++w) s += red1[w * BT + (wt * TT + j) * 32 + col];
-            mean[j] = s * (1.0f / 512.0f);
-        }
-        // biased variance of the centred values (two-pass, as accurate as the reference's LN)
-#pragma unroll
-        for (int j = 0; j < TT; ++j) {
-            float s = 0.f;
+            for (int w = 0; w < NWF; ++w) mean += red1[slot + w * BT];
+            mean *= (1.0f / 512.0f);
+            // biased variance of the centred values (two-pass, like the reference's LayerNorm)
+            float s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float d = acc[i][j][r] - mean[j];
-                    s += d * d;
+                    const float d = acc[i][j][r] - mean;
+                    s2 += d * d;
                 }
-            s += __shfl_xor(s, 32);
-            if (hf == 0) red2[wf * BT + (wt * TT + j) * 32 + col] = s;
-        }
-        __syncthreads();
+            s2 += __shfl_xor(s2, 32);
+            if (hf == 0) red2[slot + wf * BT] = s2;
+            __syncthreads();
+            float var = 0.f;
 #pragma unroll
-        for (int j = 0; j < TT; ++j) {
-            float s = 0.f;
+            for (int w = 0; w < NWF; ++w) var += red2[slot + w * BT];
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 512.0f) + eps);
+            const float mk = row_mask ? row_mask[m] : 1.0f;
 #pragma unroll
-            for (int w = 0; w < NWF; ++w) s += red2[w * BT + (wt * TT + j) * 32 + col];
-            rstd[j] = 1.0f / sqrtf(s * (1.0f / 512.0f) + eps);
-        }
+            for (int i = 0; i < FT; ++i)
 #pragma unroll
-        for (int i = 0; i < FT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = f0 + i * 32 + 8 * g + 4 * hf;
-                const float4 ga = *(const float4*)(gamma + f);
-                const float4 be = *(const float4*)(beta + f);
-#pragma unroll
-                for (int j = 0; j < TT; ++j) {
-                    const int m = t0 + j * 32 + col;
+                for (int g = 0; g < 4; ++g) {
+                    const int f = f0 + i * 32 + 8 * g + 4 * hf;
+                    const float4 ga = *(const float4*)(gamma + f);
+                    const float4 be = *(const float4*)(beta + f);
                     float v[4];
-                    v[0] = (acc[i][j][4 * g + 0] - mean[j]) * rstd[j] * ga.x + be.x;
-                    v[1] = (acc[i][j][4 * g + 1] - mean[j]) * rstd[j] * ga.y + be.y;
-                    v[2] = (acc[i][j][4 * g + 2] - mean[j]) * rstd[j] * ga.z + be.z;
-                    v[3] = (acc[i][j][4 * g + 3] - mean[j]) * rstd[j] * ga.w + be.w;
-                    if (row_mask) {
-                        const float mk = row_mask[m];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] *= mk;
-                    }
+                    v[0] = ((acc[i][j][4 * g + 0] - mean) * rstd * ga.x + be.x) * mk;
+                    v[1] = ((acc[i][j][4 * g + 1] - mean) * rstd * ga.y + be.y) * mk;
+                    v[2] = ((acc[i][j][4 * g + 2] - mean) * rstd * ga.z + be.z) * mk;
+                    v[3] = ((acc[i][j][4 * g + 3] - mean) * rstd * ga.w + be.w) * mk;
                     uint2 hi, lo;
                     split4(v, hi, lo);
                     const size_t idx = tiled_index(m, f, 32);
                     *(uint2*)(out + idx) = hi;
                     if (NP == 2) *(uint2*)(out + out_plane + idx) = lo;
                 }
-            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 };
 
