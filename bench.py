@@ -156,6 +156,13 @@ def main():
         el = tmax.item()
     finite = bool(torch.isfinite(x).all().item())
 
+    traffic = None
+    try:  # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (profiles/)
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic = json.load(f)["kernels"]["qkv_kernel:EpiQK"]["hbm_bytes_per_launch"] if (B, T, args.precision) == (256, 120, 3) else None
+    except Exception:
+        traffic = None
+
     if rank == 0:
         steps_per_s = world * K / el
         fl_step = flops_per_window_step(T) * B
@@ -183,7 +190,9 @@ def main():
             "output_finite": finite,
             "roofline": {"bound": "mfma", "kernel": "qkv_kernel (Q/K/V projection GEMM, 53% of step FLOPs)",
                          "achieved": qkv_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (qkv_ach / PEAK_BF16_TFLOPS) if qkv_ach else None, "traffic": None,
+                         "frac": (qkv_ach / PEAK_BF16_TFLOPS) if qkv_ach else None, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 PMC pass, FETCH_SIZE x2 + WRITE_SIZE); "
+                                         "algorithmic bytes per launch = 4*B*L*(512 + 3072) + weights = 450 MB",
                          "launch_us": k_us, "launches": k_n,
                          "note": "algorithmic FLOPs (1x) over measured launch time; split-bf16 issues 3 MFMAs per product, "
                                  "so MFMA-pipe utilisation is 3x this fraction"},

@@ -241,7 +241,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             HIP_TRY(hipGetLastError());
         }
         if (last_dbg && (io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V))
-            continue;
+            return 0;
         // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
         {
             ProfScope ps(c, EGOEGO_K_ATTN, s);
