@@ -1,0 +1,210 @@
+"""Callers either side of the sampling loop: head-condition mask, the overlapping
+sliding-window harness with heading canonicalisation, and the post-loop conversion of a sampled window
+back to SMPL-H parameters.
+
+Mirrors, with the same names and argument meaning,
+  Trainer.prep_head_condition_mask                      trainer_amass_cond_motion_diffusion.py:210-221
+  Trainer.full_body_gen_cond_head_pose_sliding_window   trainer_amass_cond_motion_diffusion.py:261-276
+  CondGaussianDiffusion.p_sample_loop_sliding_window_w_canonical / sample_sliding_window_w_canonical /
+  convert_model_res_to_data                             egoego/model/transformer_cond_diffusion_model.py:329-555
+  rotate_at_frame_smplh                                 egoego/lafan1/utils.py:111-137
+  AMASSDataset.{normalize,de_normalize}_jpos_min_max, fk_smpl, quat_ik_torch
+                                                        egoego/data/amass_diffusion_dataset.py:109-125, 265-293, 379-392
+
+Differences from the reference, on purpose: everything stays on the GPU (the reference round-trips through
+numpy twice per window, M:362-368, 435-440); the 1000 diffusion steps of a window run inside ONE call of the
+HIP sample loop, with the per-step overwrite of the first 10 frames (M:395-397) done by the step kernel's
+`prefix` argument; 6D -> matrix uses the HIP kernel.  No reference oracle can run here (pytorch3d /
+human_body_prior / SMPL-H are absent): parity for this tier is against oracle/harness_oracle.py, an
+independent numpy + scipy restatement, and is "unpinned" in the sense of SURVEY.md §8c.
+"""
+import numpy as np
+import torch
+
+from . import rotations as R
+from . import _lib
+
+# first 22 entries of the SMPL-H kintree (amass_diffusion_dataset.py:83-90 reads them from the licensed npz)
+SMPLH_PARENTS_22 = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19)
+HEAD_IDX = 15
+OVERLAP = 10  # frames shared by consecutive windows (M:350)
+
+
+def prep_head_condition_mask(data, joint_idx=HEAD_IDX):
+    """1 = to be generated, 0 = given head position (3) and 6D rotation (6) dims."""
+    mask = torch.ones_like(data)
+    mask[:, :, joint_idx * 3:joint_idx * 3 + 3] = 0
+    mask[:, :, 22 * 3 + joint_idx * 6:22 * 3 + joint_idx * 6 + 6] = 0
+    return mask
+
+
+class SkeletonStats:
+    """The three `ds` methods the harness needs, for users without the reference's AMASSDataset
+    (which requires human_body_prior + licensed SMPL-H): min/max joint normalisation and quaternion FK
+    over given rest-pose offsets.  Any object with the same three methods can be passed instead."""
+
+    def __init__(self, global_jpos_min, global_jpos_max, rest_human_offsets, parents=SMPLH_PARENTS_22):
+        self.global_jpos_min = torch.as_tensor(global_jpos_min, dtype=torch.float32).reshape(1, 22, 3)
+        self.global_jpos_max = torch.as_tensor(global_jpos_max, dtype=torch.float32).reshape(1, 22, 3)
+        self.rest_human_offsets = torch.as_tensor(rest_human_offsets, dtype=torch.float32).reshape(1, 22, 3)
+        self.parents = tuple(int(p) for p in parents)
+
+    def normalize_jpos_min_max(self, ori_jpos):
+        lo, hi = self.global_jpos_min.to(ori_jpos.device), self.global_jpos_max.to(ori_jpos.device)
+        return (ori_jpos - lo) / (hi - lo) * 2 - 1
+
+    def de_normalize_jpos_min_max(self, normalized_jpos):
+        lo, hi = self.global_jpos_min.to(normalized_jpos.device), self.global_jpos_max.to(normalized_jpos.device)
+        return (normalized_jpos + 1) * 0.5 * (hi - lo) + lo
+
+    def fk_smpl(self, root_trans, lrot_aa):
+        """root_trans [N,3], local axis-angle [N,22,3] -> (global quaternions [N,22,4], global joints [N,22,3])."""
+        lrot = R.matrix_to_quaternion(R.axis_angle_to_matrix(lrot_aa))
+        lpos = self.rest_human_offsets.to(lrot.device).repeat(lrot.shape[0], 1, 1)
+        gp, gr = [lpos[..., :1, :]], [lrot[..., :1, :]]
+        for i in range(1, len(self.parents)):
+            p = self.parents[i]
+            gp.append(R.quaternion_apply(gr[p], lpos[..., i:i + 1, :]) + gp[p])
+            gr.append(R.quaternion_multiply(gr[p], lrot[..., i:i + 1, :]))
+        return torch.cat(gr, dim=-2), torch.cat(gp, dim=-2) + root_trans[:, None, :]
+
+
+def rotate_at_frame(trans, quat, cano_t_idx=0):
+    """Heading canonicalisation on the device: rotate about z so that the facing direction of frame
+    `cano_t_idx` projects onto +x.  trans [B,T,3], quat [B,T,4] -> (trans', quat', yrot [B,1,1,4])."""
+    key = quat[:, cano_t_idx:cano_t_idx + 1, :]
+    ex = torch.zeros_like(key[..., :3])
+    ex[..., 0] = 1
+    t = 2.0 * torch.cross(key[..., 1:], ex, dim=-1)
+    fwd = ex + key[..., :1] * t + torch.cross(key[..., 1:], t, dim=-1)
+    fwd = fwd * fwd.new_tensor([1, 1, 0])
+    fwd = fwd / (fwd.norm(dim=-1, keepdim=True) + 1e-8)
+    # quaternion taking +x onto fwd: (|x||f| + x.f, x cross f), normalised
+    w = torch.sqrt((ex * ex).sum(-1) * (fwd * fwd).sum(-1))[..., None] + (ex * fwd).sum(-1, keepdim=True)
+    yrot = torch.cat((w, torch.cross(ex, fwd, dim=-1)), -1)
+    yrot = yrot / (yrot.norm(dim=-1, keepdim=True) + 1e-8)
+    inv = yrot * yrot.new_tensor([1, -1, -1, -1])
+    new_q = R.quaternion_raw_multiply(inv.expand_as(quat), quat)
+    ti = 2.0 * torch.cross(inv[..., 1:].expand_as(trans), trans, dim=-1)
+    new_x = trans + inv[..., :1] * ti + torch.cross(inv[..., 1:].expand_as(trans), ti, dim=-1)
+    return new_x, new_q, yrot[:, None]
+
+
+def quat_ik(grot_mat, parents=SMPLH_PARENTS_22):
+    """Global -> local joint rotations (amass_diffusion_dataset.py:109-125)."""
+    grot = R.matrix_to_quaternion(grot_mat)
+    par = list(parents[1:])
+    res = torch.cat((grot[..., :1, :],
+                     R.quaternion_multiply(R.quaternion_invert(grot[..., par, :]), grot[..., 1:, :])), dim=-2)
+    return R.quaternion_to_matrix(res)
+
+
+def convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_head_jpos=None, parents=SMPLH_PARENTS_22):
+    """M:469-525: normalised window [B,T,198] -> (local axis-angle [B,T,22,3], root position [B,T,3],
+    head position [B,T,3]) in the ORIGINAL (un-canonicalised) heading.  recover_rot_quat: [B,1,1,4]
+    (tensor or numpy)."""
+    bs = all_res_list.shape[0]
+    dev = all_res_list.device
+    jpos = ds.de_normalize_jpos_min_max(all_res_list[:, :, :66].reshape(-1, 22, 3)).reshape(bs, -1, 22, 3)
+    n = jpos.shape[1]
+    rot6d = all_res_list[:, :, 66:].reshape(bs, n, 22, 6)
+    rec = torch.as_tensor(recover_rot_quat).to(dev, jpos.dtype).reshape(bs, 1, 1, 4)
+    gquat = R.matrix_to_quaternion(R.rotation_6d_to_matrix(rot6d))
+    ori_gquat = R.quaternion_multiply(rec.expand_as(gquat), gquat)
+    rec_t = rec.reshape(bs, 1, 4).expand(bs, n, 4)
+    root = R.quaternion_apply(rec_t, jpos[:, :, 0, :])
+    head = R.quaternion_apply(rec_t, jpos[:, :, HEAD_IDX, :])
+    local = quat_ik(R.quaternion_to_matrix(ori_gquat).reshape(-1, 22, 3, 3), parents).reshape(bs, n, 22, 3, 3)
+    return R.matrix_to_axis_angle(local), root, head
+
+
+@torch.no_grad()
+def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos, global_head_jquat, cond_mask,
+                                             noise=None, parents=SMPLH_PARENTS_22):
+    """M:329-467.  Windows of `model.seq_len` frames, stride seq_len-10; window k+1 is conditioned on the
+    last 10 frames of window k, re-canonicalised, by overwriting its first 10 frames after every step.
+
+    noise (tests): {'x_all': [B,T,D], 'cond': [per-window [B,Tw,D]], 'steps': [per-window [S,B,Tw,D]]}.
+    """
+    eng = model.hip_engine()
+    device = model.betas.device
+    b = shape[0]
+    S = model.num_timesteps
+    seq_len = model.seq_len
+    stride = seq_len - OVERLAP
+    x_all = noise["x_all"].to(device).float() if noise is not None else torch.randn(shape, device=device)
+    jpos_all = global_head_jpos.to(device)
+    jquat_all = global_head_jquat.to(device)
+    num_steps = jpos_all.shape[1]
+    whole_aa = whole_root = whole_head = None
+    prefix = None
+    w_idx = 0
+    for t_idx in range(0, num_steps, stride):
+        curr_x = x_all[:, t_idx:t_idx + seq_len].contiguous().clone()
+        if curr_x.shape[1] <= seq_len - stride:
+            break
+        cur_quat = jquat_all[:, t_idx:t_idx + seq_len]
+        cur_jpos = jpos_all[:, t_idx:t_idx + seq_len]
+        al_trans, al_quat, recover = rotate_at_frame(cur_jpos, cur_quat, 0)
+        move0 = al_trans[:, 0:1, :].clone()
+        move0[:, :, 2] = 0
+        al_trans = al_trans - move0
+        al_6d = R.matrix_to_rotation_6d(R.quaternion_to_matrix(al_quat))
+        Tw = al_6d.shape[1]
+        x_start = torch.zeros(b, Tw, 198, device=device)
+        x_start[:, :, HEAD_IDX * 3:HEAD_IDX * 3 + 3] = al_trans.float()
+        x_start[:, :, 66 + HEAD_IDX * 6:66 + HEAD_IDX * 6 + 6] = al_6d.float()
+        x_start[:, :, :66] = ds.normalize_jpos_min_max(x_start[:, :, :66].reshape(-1, 22, 3)).reshape(b, -1, 66)
+        cm = cond_mask[:, t_idx:t_idx + seq_len].to(device)
+        cn = noise["cond"][w_idx].to(device) if noise is not None else torch.randn_like(x_start)
+        x_cond = (x_start * (1.0 - cm) + cm * cn).float().contiguous()
+        pfx = prefix if t_idx > 0 else None
+        if noise is not None:
+            eng.sample_loop_(curr_x, x_cond, S - 1, S, noise=noise["steps"][w_idx].to(device).float().contiguous(), prefix=pfx)
+        elif model.sampling_rng == "philox":
+            eng.sample_loop_(curr_x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=model.philox_seed + w_idx,
+                             prefix=pfx)
+        else:
+            for i in reversed(range(S)):
+                eng.sample_loop_(curr_x, x_cond, i, 1, noise=torch.randn_like(curr_x)[None], prefix=pfx)
+        aa, root, head = convert_model_res_to_data(ds, curr_x, recover, cur_jpos, parents)
+        if t_idx == 0:
+            whole_aa, whole_root, whole_head = aa, root, head
+        else:
+            move = whole_head[:, -1:, :] - head[:, seq_len - stride - 1:seq_len - stride, :]
+            root = root + move
+            head = head + move
+            whole_aa = torch.cat((whole_aa, aa[:, seq_len - stride:]), dim=1)
+            whole_root = torch.cat((whole_root, root[:, seq_len - stride:]), dim=1)
+            whole_head = torch.cat((whole_head, head[:, seq_len - stride:]), dim=1)
+        # condition for the next window: the last `OVERLAP` frames, re-canonicalised and re-normalised
+        gq, gj = ds.fk_smpl(root.reshape(-1, 3), aa.reshape(-1, 22, 3))
+        gq = gq.reshape(b, -1, 22, 4)[:, -seq_len + stride:]
+        gj = gj.reshape(b, -1, 22, 3)[:, -seq_len + stride:]
+        t_trans, _, t_rec = rotate_at_frame(gj[:, :, HEAD_IDX, :], gq[:, :, HEAD_IDX, :], 0)
+        t_move = t_trans[:, 0:1, :].clone()
+        t_move[:, :, 2] = 0
+        inv = R.quaternion_invert(t_rec.float()).expand(b, gj.shape[1], 22, 4)
+        pj = R.quaternion_apply(inv, gj) - t_move[:, :, None, :]
+        pj = ds.normalize_jpos_min_max(pj.reshape(-1, 22, 3)).reshape(b, -1, 66)
+        p6 = R.matrix_to_rotation_6d(R.quaternion_to_matrix(R.quaternion_multiply(inv, gq))).reshape(b, -1, 132)
+        prefix = torch.cat((pj, p6), dim=-1).float().contiguous()
+        w_idx += 1
+    return whole_aa, whole_root
+
+
+@torch.no_grad()
+def sample_sliding_window_w_canonical(model, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None):
+    model.denoise_fn.eval()
+    res = p_sample_loop_sliding_window_w_canonical(model, ds, x_start.shape, global_head_jpos, global_head_jquat,
+                                                   cond_mask, noise=noise)
+    model.denoise_fn.train()
+    return res
+
+
+@torch.no_grad()
+def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None):
+    """head_pose [B,T,7] = xyz + quaternion (w,x,y,z) -> (local axis-angle [B,T',22,3], root [B,T',3])."""
+    jpos, jquat = head_pose[:, :, :3], head_pose[:, :, 3:]
+    data = torch.zeros(head_pose.shape[0], head_pose.shape[1], 198, device=head_pose.device)
+    return sample_sliding_window_w_canonical(model, ds, jpos, jquat, data, prep_head_condition_mask(data), noise=noise)

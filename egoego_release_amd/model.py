@@ -328,6 +328,23 @@ class CondGaussianDiffusion(nn.Module):
         eng.ddim_loop_(x, x_cond, ts)
         return x
 
+    # ------------------------------------------------------------------ sliding-window harness (harness.py)
+    def convert_model_res_to_data(self, ds, all_res_list, recover_rot_quat, curr_global_head_jpos=None):
+        from . import harness
+        return harness.convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_head_jpos)
+
+    @torch.no_grad()
+    def p_sample_loop_sliding_window_w_canonical(self, ds, shape, global_head_jpos, global_head_jquat, cond_mask, noise=None):
+        from . import harness
+        return harness.p_sample_loop_sliding_window_w_canonical(self, ds, shape, global_head_jpos, global_head_jquat,
+                                                                cond_mask, noise=noise)
+
+    @torch.no_grad()
+    def sample_sliding_window_w_canonical(self, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None):
+        from . import harness
+        return harness.sample_sliding_window_w_canonical(self, ds, global_head_jpos, global_head_jquat, x_start, cond_mask,
+                                                         noise=noise)
+
     # ------------------------------------------------------------------ training half (plain PyTorch)
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise

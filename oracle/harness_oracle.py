@@ -1,0 +1,179 @@
+"""CPU oracle for the callers either side of the sampling loop (sliding-window harness and the post-loop
+conversion to SMPL-H parameters).  TEST INFRASTRUCTURE ONLY — see oracle/egoego_oracle.py.
+
+It follows the reference line by line
+  p_sample_loop_sliding_window_w_canonical   egoego/model/transformer_cond_diffusion_model.py:329-467
+  convert_model_res_to_data                  egoego/model/transformer_cond_diffusion_model.py:469-525
+  rotate_at_frame_smplh & quaternion helpers egoego/lafan1/utils.py:5-137
+  quat_ik_torch / fk_smpl / min-max          egoego/data/amass_diffusion_dataset.py:109-125, 265-293, 379-392
+but does the rotation algebra with numpy + scipy.spatial.transform.Rotation (an implementation independent of
+egoego_release_amd/rotations.py).  The reference itself cannot run here (pytorch3d, human_body_prior and the
+SMPL-H model are absent), so this oracle is PARITY UNPINNED: it is anchored on mathematical identities
+(tests/test_harness.py), not on reference outputs.
+"""
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as Rot
+
+from . import egoego_oracle as O
+
+PARENTS = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19)
+HEAD = 15
+
+
+# ---- lafan1/utils.py:5-109, real-first quaternions, float64 numpy
+def _normalize(x, eps=1e-8):
+    return x / (np.sqrt(np.sum(x * x, axis=-1, keepdims=True)) + eps)
+
+
+def quat_inv(q):
+    return np.asarray([1, -1, -1, -1], dtype=q.dtype) * q
+
+
+def quat_mul(x, y):
+    x0, x1, x2, x3 = x[..., 0:1], x[..., 1:2], x[..., 2:3], x[..., 3:4]
+    y0, y1, y2, y3 = y[..., 0:1], y[..., 1:2], y[..., 2:3], y[..., 3:4]
+    return np.concatenate([y0 * x0 - y1 * x1 - y2 * x2 - y3 * x3, y0 * x1 + y1 * x0 - y2 * x3 + y3 * x2,
+                           y0 * x2 + y1 * x3 + y2 * x0 - y3 * x1, y0 * x3 - y1 * x2 + y2 * x1 + y3 * x0], axis=-1)
+
+
+def quat_mul_vec(q, x):
+    t = 2.0 * np.cross(q[..., 1:], x)
+    return x + q[..., 0][..., None] * t + np.cross(q[..., 1:], t)
+
+
+def quat_between(x, y):
+    return np.concatenate([np.sqrt(np.sum(x * x, -1) * np.sum(y * y, -1))[..., None] + np.sum(x * y, -1)[..., None],
+                           np.cross(x, y)], axis=-1)
+
+
+def rotate_at_frame_smplh(root_trans, root_quat, cano_t_idx=0):
+    """lafan1/utils.py:111-137."""
+    gq, gx = root_quat[:, None], root_trans[:, None]
+    key = gq[:, :, cano_t_idx:cano_t_idx + 1, :]
+    ex = np.array([1.0, 0, 0])[None, None, None, :]
+    fwd = _normalize(np.array([1.0, 1, 0])[None, None, None, :] * quat_mul_vec(key, ex))
+    yrot = _normalize(quat_between(np.array([1.0, 0, 0]), fwd))
+    return quat_mul_vec(quat_inv(yrot), gx)[:, 0], quat_mul(quat_inv(yrot), gq)[:, 0], yrot
+
+
+# ---- pytorch3d-equivalent pieces through scipy (scalar-last there)
+def _to_scipy(q):
+    return np.concatenate([q[..., 1:], q[..., :1]], -1)
+
+
+def _from_scipy(q):
+    q = np.concatenate([q[..., 3:], q[..., :3]], -1)
+    return np.where(q[..., :1] < 0, -q, q)
+
+
+def quat_to_mat(q):
+    return Rot.from_quat(_to_scipy(q).reshape(-1, 4)).as_matrix().reshape(q.shape[:-1] + (3, 3))
+
+
+def mat_to_quat(m):
+    return _from_scipy(Rot.from_matrix(m.reshape(-1, 3, 3)).as_quat()).reshape(m.shape[:-2] + (4,))
+
+
+def rot6d_to_mat(d6):
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = a1 / np.maximum(np.linalg.norm(a1, axis=-1, keepdims=True), 1e-12)
+    b2 = a2 - (b1 * a2).sum(-1, keepdims=True) * b1
+    b2 = b2 / np.maximum(np.linalg.norm(b2, axis=-1, keepdims=True), 1e-12)
+    return np.stack([b1, b2, np.cross(b1, b2)], -2)
+
+
+def std_mul(a, b):
+    q = quat_mul(a, b)
+    return np.where(q[..., :1] < 0, -q, q)
+
+
+class SkeletonOracle:
+    """ds stand-in: min/max normalisation (dataset:379-392) and quaternion FK (dataset:265-293)."""
+
+    def __init__(self, jmin, jmax, offsets):
+        self.lo = np.asarray(jmin, np.float64).reshape(1, 22, 3)
+        self.hi = np.asarray(jmax, np.float64).reshape(1, 22, 3)
+        self.off = np.asarray(offsets, np.float64).reshape(22, 3)
+
+    def norm(self, j):
+        return (j - self.lo) / (self.hi - self.lo) * 2 - 1
+
+    def denorm(self, j):
+        return (j + 1) * 0.5 * (self.hi - self.lo) + self.lo
+
+    def fk(self, root, aa):
+        n = aa.shape[0]
+        lq = mat_to_quat(Rot.from_rotvec(aa.reshape(-1, 3)).as_matrix().reshape(n, 22, 3, 3))
+        gp, gr = [np.repeat(self.off[None, :1], n, 0)], [lq[:, :1]]
+        for i in range(1, 22):
+            p = PARENTS[i]
+            gp.append(quat_mul_vec(gr[p], np.repeat(self.off[None, i:i + 1], n, 0)) + gp[p])
+            gr.append(std_mul(gr[p], lq[:, i:i + 1]))
+        return np.concatenate(gr, 1), np.concatenate(gp, 1) + root[:, None, :]
+
+
+def convert_model_res_to_data(ds, x, recover):
+    """M:469-525.  x [B,T,198] float array, recover [B,1,1,4]."""
+    bs = x.shape[0]
+    jpos = ds.denorm(x[:, :, :66].reshape(-1, 22, 3)).reshape(bs, -1, 22, 3)
+    n = jpos.shape[1]
+    gq = mat_to_quat(rot6d_to_mat(x[:, :, 66:].reshape(bs, n, 22, 6)))
+    oq = std_mul(np.broadcast_to(recover, gq.shape), gq)
+    rec = np.broadcast_to(recover.reshape(bs, 1, 4), (bs, n, 4))
+    root, head = quat_mul_vec(rec, jpos[:, :, 0]), quat_mul_vec(rec, jpos[:, :, HEAD])
+    par = list(PARENTS[1:])
+    lq = np.concatenate([oq[..., :1, :], std_mul(quat_inv(oq[..., par, :]), oq[..., 1:, :])], -2)
+    aa = Rot.from_quat(_to_scipy(lq).reshape(-1, 4)).as_rotvec().reshape(bs, n, 22, 3)
+    return aa, root, head
+
+
+def sliding_window(sd, sched, ds, seq_len, S, head_jpos, head_quat, cond_mask, noise, objective="pred_x0"):
+    """M:329-467 with every random draw supplied: noise = {'x_all', 'cond': [...], 'steps': [...]}."""
+    b, T = head_jpos.shape[:2]
+    stride = seq_len - 10
+    x_all = noise["x_all"].double().numpy()
+    whole = None
+    prev6 = prevj = None
+    w = 0
+    for t_idx in range(0, T, stride):
+        cur = torch.from_numpy(x_all[:, t_idx:t_idx + seq_len]).float()
+        if cur.shape[1] <= seq_len - stride:
+            break
+        q, p = head_quat[:, t_idx:t_idx + seq_len], head_jpos[:, t_idx:t_idx + seq_len]
+        a_t, a_q, rec = rotate_at_frame_smplh(p, q, 0)
+        mv = a_t[:, 0:1].copy()
+        mv[:, :, 2] = 0
+        a_t = a_t - mv
+        a6 = quat_to_mat(a_q)[..., :2, :].reshape(b, -1, 6)
+        xs = np.zeros((b, a6.shape[1], 198))
+        xs[:, :, 45:48] = a_t
+        xs[:, :, 156:162] = a6
+        xs[:, :, :66] = ds.norm(xs[:, :, :66].reshape(-1, 22, 3)).reshape(b, -1, 66)
+        xs = torch.from_numpy(xs).float()
+        cm = cond_mask[:, t_idx:t_idx + seq_len]
+        xc = xs * (1.0 - cm) + cm * noise["cond"][w]
+        for i, t in enumerate(reversed(range(S))):
+            cur = O.p_sample(sd, sched, cur, torch.full((b,), t, dtype=torch.long), xc, noise["steps"][w][i], objective)
+            if t_idx > 0:  # M:395-397
+                cur[:, :10, 66:] = prev6
+                cur[:, :10, :66] = prevj
+        aa, root, head = convert_model_res_to_data(ds, cur.double().numpy(), rec)
+        if t_idx == 0:
+            whole = [aa, root, head]
+        else:
+            move = whole[2][:, -1:] - head[:, seq_len - stride - 1:seq_len - stride]
+            root, head = root + move, head + move
+            whole = [np.concatenate([a, c[:, seq_len - stride:]], 1) for a, c in zip(whole, (aa, root, head))]
+        gq, gj = ds.fk(root.reshape(-1, 3), aa.reshape(-1, 22, 3))
+        gq = gq.reshape(b, -1, 22, 4)[:, -seq_len + stride:]
+        gj = gj.reshape(b, -1, 22, 3)[:, -seq_len + stride:]
+        t_t, _, t_rec = rotate_at_frame_smplh(gj[:, :, HEAD], gq[:, :, HEAD], 0)
+        t_mv = t_t[:, 0:1].copy()
+        t_mv[:, :, 2] = 0
+        inv = np.broadcast_to(quat_inv(t_rec), gq.shape)
+        pj = quat_mul_vec(inv, gj) - t_mv[:, :, None, :]
+        prevj = torch.from_numpy(ds.norm(pj.reshape(-1, 22, 3)).reshape(b, -1, 66)).float()
+        prev6 = torch.from_numpy(quat_to_mat(std_mul(inv, gq))[..., :2, :].reshape(b, -1, 132)).float()
+        w += 1
+    return whole[0], whole[1]

@@ -1,0 +1,118 @@
+"""Callers either side of the loop: rotation algebra, canonicalisation, post-loop conversion, and the
+overlapping sliding-window harness.  Product code (torch/HIP) vs the independent numpy+scipy oracle."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial.transform import Rotation as Rot
+
+from egoego_release_amd import ModelConfig, make_weights, harness, rotations as R
+from oracle import egoego_oracle as O
+from oracle import harness_oracle as HO
+
+
+def _rand_quat(shape, seed):
+    g = np.random.default_rng(seed)
+    q = g.standard_normal(shape + (4,))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    return np.where(q[..., :1] < 0, -q, q)
+
+
+def _skeleton(seed=0):
+    g = np.random.default_rng(seed)
+    off = g.uniform(-0.2, 0.2, (22, 3))
+    off[0] = 0
+    jmin = g.uniform(-2.0, -1.0, (22, 3))
+    jmax = g.uniform(1.0, 2.0, (22, 3))
+    return harness.SkeletonStats(jmin, jmax, off), HO.SkeletonOracle(jmin, jmax, off)
+
+
+def test_rotation_algebra_against_scipy():
+    q = _rand_quat((200,), 1)
+    m = R.quaternion_to_matrix(torch.from_numpy(q))
+    assert np.abs(m.numpy() - HO.quat_to_mat(q)).max() < 1e-12
+    assert np.abs(R.matrix_to_quaternion(m).numpy() - q).max() < 1e-7
+    aa = R.matrix_to_axis_angle(m).numpy()
+    assert np.abs(aa - Rot.from_matrix(m.numpy()).as_rotvec()).max() < 1e-6
+    assert np.abs(R.axis_angle_to_matrix(torch.from_numpy(aa)).numpy() - m.numpy()).max() < 1e-9
+    p = np.random.default_rng(2).standard_normal((200, 3))
+    assert np.abs(R.quaternion_apply(torch.from_numpy(q), torch.from_numpy(p)).numpy() - HO.quat_mul_vec(q, p)).max() < 1e-12
+    q2 = _rand_quat((200,), 3)
+    assert np.abs(R.quaternion_multiply(torch.from_numpy(q), torch.from_numpy(q2)).numpy() - HO.std_mul(q, q2)).max() < 1e-12
+    d6 = R.matrix_to_rotation_6d(m)
+    assert np.abs(R.rotation_6d_to_matrix(d6).numpy() - m.numpy()).max() < 1e-9
+    # small-angle branch of axis-angle
+    tiny = torch.tensor([[1e-9, 0.0, 0.0], [0.0, 0.0, 0.0]], dtype=torch.float64)
+    assert torch.allclose(R.matrix_to_axis_angle(R.axis_angle_to_matrix(tiny)), tiny, atol=1e-12)
+
+
+def test_rotate_at_frame_matches_oracle_and_faces_x():
+    q, p = _rand_quat((3, 40), 4), np.random.default_rng(5).standard_normal((3, 40, 3))
+    t1, q1, y1 = harness.rotate_at_frame(torch.from_numpy(p), torch.from_numpy(q), 0)
+    t2, q2, y2 = HO.rotate_at_frame_smplh(p, q, 0)
+    assert np.abs(t1.numpy() - t2).max() < 1e-12 and np.abs(q1.numpy() - q2).max() < 1e-12
+    assert np.abs(y1.numpy() - y2).max() < 1e-12
+    # after canonicalisation the facing direction of frame 0 has no y component and positive x
+    f = HO.quat_mul_vec(q2[:, 0], np.array([1.0, 0, 0]))
+    assert np.abs(f[:, 1]).max() < 1e-7 and (f[:, 0] > 0).all()
+
+
+def test_condition_mask_and_stats_roundtrip():
+    d = torch.zeros(2, 7, 198)
+    m = harness.prep_head_condition_mask(d)
+    assert torch.equal(m, O.head_condition_mask(d.shape))
+    ds, dso = _skeleton()
+    j = torch.randn(5, 22, 3, dtype=torch.float64)
+    assert torch.allclose(ds.de_normalize_jpos_min_max(ds.normalize_jpos_min_max(j.float())), j.float(), atol=1e-5)
+    aa = torch.from_numpy(np.random.default_rng(7).standard_normal((6, 22, 3)) * 0.5)
+    root = torch.randn(6, 3, dtype=torch.float64)
+    gq, gj = ds.fk_smpl(root.float(), aa.float())
+    gq2, gj2 = dso.fk(root.numpy(), aa.numpy())
+    assert np.abs(gj.numpy() - gj2).max() < 1e-5 and np.abs(gq.numpy() - gq2).max() < 1e-5
+
+
+def test_convert_model_res_to_data_cpu_vs_oracle():
+    ds, dso = _skeleton(1)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 12, 198, generator=g) * 2 - 1
+    rec = _rand_quat((2, 1, 1), 9)
+    aa, root, head = harness.convert_model_res_to_data(ds, x, rec)
+    aa2, root2, head2 = HO.convert_model_res_to_data(dso, x.double().numpy(), rec)
+    assert np.abs(root.numpy() - root2).max() < 1e-5 and np.abs(head.numpy() - head2).max() < 1e-5
+    # compare rotations, not raw axis-angle (angle ~ pi is sign-ambiguous)
+    d = Rot.from_rotvec(aa.reshape(-1, 3).numpy()) * Rot.from_rotvec(aa2.reshape(-1, 3)).inv()
+    assert np.abs(d.magnitude()).max() < 2e-3  # random 6D inputs can be ill-conditioned
+    assert np.median(np.abs(d.magnitude())) < 1e-5
+
+
+@pytest.mark.gpu
+def test_sliding_window_hip_vs_oracle():
+    """Two overlapping windows (40 + 20 frames at seq_len 40), 6 diffusion steps, identical injected noise:
+    exercises canonicalisation, the per-step prefix in-painting inside the HIP loop, the conversion chain,
+    stitching and FK-based re-canonicalisation."""
+    from egoego_release_amd.model import CondGaussianDiffusion
+    seq_len, S, B, T = 40, 6, 2, 50
+    cfg = ModelConfig(max_timesteps=seq_len + 1)
+    sd = make_weights(cfg, 0)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    m.num_timesteps = S
+    ds, dso = _skeleton(2)
+    rng = np.random.default_rng(11)
+    head_q = _rand_quat((B, T), 12)
+    head_p = np.cumsum(rng.standard_normal((B, T, 3)) * 0.01, 1) + np.array([0.0, 0.0, 1.5])
+    head_pose = torch.from_numpy(np.concatenate([head_p, head_q], -1)).float()
+    g = torch.Generator().manual_seed(5)
+    wins = [(0, 40), (30, 50)]
+    noise = {"x_all": torch.randn(B, T, 198, generator=g),
+             "cond": [torch.randn(B, b - a, 198, generator=g) for a, b in wins],
+             "steps": [torch.randn(S, B, b - a, 198, generator=g) for a, b in wins]}
+    aa, root = harness.full_body_gen_cond_head_pose_sliding_window(m, ds, head_pose.cuda(), noise=noise)
+    assert aa.shape == (B, T, 22, 3) and root.shape == (B, T, 3)
+    cm = O.head_condition_mask((B, T, 198))
+    aa2, root2 = HO.sliding_window(sd, O.make_schedule(1000), dso, seq_len, S, head_pose[..., :3].double().numpy(),
+                                   head_pose[..., 3:].double().numpy(), cm, noise)
+    assert np.abs(root.cpu().numpy() - root2).max() < 2e-3
+    d = Rot.from_rotvec(aa.reshape(-1, 3).cpu().numpy()) * Rot.from_rotvec(aa2.reshape(-1, 3)).inv()
+    ang = np.abs(d.magnitude())
+    assert np.median(ang) < 1e-3 and np.quantile(ang, 0.99) < 2e-2, (np.median(ang), np.quantile(ang, 0.99), ang.max())
