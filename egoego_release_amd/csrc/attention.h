@@ -34,16 +34,14 @@ struct AttnArgs {
 };
 
 template <int KT, int NP>
-__global__ __launch_bounds__(256, (KT <= 4 ? 2 : 1)) void attn_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock, char* smem) {
     constexpr int NCH = KT * NP;                  // 16-byte chunks per thread per phase
     constexpr int STAGE_BYTES = KT * NP * 4096;   // K chunk: KT tiles x NP planes x 4 k-steps x 1 KiB
     constexpr int Lp = KT * 32;
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63;
     const int hf = lane >> 5, col = lane & 31;
-    const int bh = blockIdx.y + a.bh0;
-    const int qt_raw = blockIdx.x * 4 + wave;
+    const int qt_raw = qblock * 4 + wave;
     const bool active = qt_raw < KT;
     const int qt = active ? qt_raw : KT - 1;
 
@@ -183,14 +181,15 @@ __global__ __launch_bounds__(256, (KT <= 4 ? 2 : 1)) void attn_kernel(AttnArgs a
 #pragma unroll
                 for (int dt2 = 0; dt2 < 2; ++dt2)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int f = h * 256 + (2 * (ph - 4) + dt2) * 32 + 8 * g + 4 * hf;
-                        float v[4] = {o[dt2][4 * g + 0], o[dt2][4 * g + 1], o[dt2][4 * g + 2], o[dt2][4 * g + 3]};
-                        uint2 hi, lo;
-                        split4(v, hi, lo);
-                        const size_t idx = tiled_index(m, f, a.HD16);
-                        *(uint2*)(a.o + idx) = hi;
-                        if constexpr (NP == 2) *(uint2*)(a.o + a.o_plane + idx) = lo;
+                    for (int jj = 0; jj < 2; ++jj) {
+                        float v[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = o[dt2][8 * jj + c];
+                        u32x4 hi, lo;
+                        split8(v, hi, lo);
+                        const size_t idx = acc_slot(m, h * 256 + (2 * (ph - 4) + dt2) * 32, jj, hf, a.HD16);
+                        *(u32x4*)(a.o + idx) = hi;
+                        if constexpr (NP == 2) *(u32x4*)(a.o + a.o_plane + idx) = lo;
                     }
             }
         }
@@ -203,4 +202,10 @@ __global__ __launch_bounds__(256, (KT <= 4 ? 2 : 1)) void attn_kernel(AttnArgs a
     phase(std::integral_constant<int, 5>{});
     phase(std::integral_constant<int, 6>{});
     phase(std::integral_constant<int, 7>{});
+}
+
+template <int KT, int NP>
+__global__ __launch_bounds__(256, (KT <= 4 ? 2 : 1)) void attn_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body<KT, NP>(a, (int)blockIdx.y + a.bh0, (int)blockIdx.x, smem);
 }

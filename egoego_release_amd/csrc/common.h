@@ -35,6 +35,49 @@ EG_HD size_t tiled_index(int r, int k, int K16) {
            (size_t)((r & 31) << 3) + (size_t)(k & 7);
 }
 
+// "Accumulator order" of the k (feature) axis.  In the swapped MFMA accumulator a lane owns features
+// 8g + 4*hf + c (g = 0..3, c = 0..3) of a 32-feature tile, i.e. two runs of 4 inside every group of 16.
+// Storing feature 8a + 4b + c of each group of 16 at position 8b + 4a + c (bits 2 and 3 swapped — an
+// involution) makes those two runs ONE run of 8: every epilogue store / residual load becomes a single
+// 16-byte access per lane and a whole wave writes one contiguous KiB.  A contraction does not care about
+// the order of k as long as both operands agree, so every activation is kept in this order and the weights
+// that consume it are packed with the same permutation along K (Q and K share it along d_k).
+EG_HD int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+
+// Element index of (row r, feature f) in a fragment-tiled plane kept in accumulator order.
+EG_HD size_t tiled_index_acc(int r, int f, int K16) { return tiled_index(r, swap23(f), K16); }
+
+// Split eight fp32 values and pack them as 2 x (8 bf16 = 16 bytes).
+EG_D void split8(const float v[8], u32x4& hi, u32x4& lo) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (__bf16)v[i];
+        l[i] = (__bf16)(v[i] - (float)h[i]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+EG_D void unpack8(u32x4 hi, u32x4 lo, float v[8]) {
+    bf16x8 h = __builtin_bit_cast(bf16x8, hi);
+    bf16x8 l = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i] + (float)l[i];
+}
+
+EG_D void unpack8_hi(u32x4 hi, float v[8]) {
+    bf16x8 h = __builtin_bit_cast(bf16x8, hi);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+
+// Swapped-accumulator helper: for accumulator tile registers 8*jj .. 8*jj+7 of lane (col, hf), the element
+// offset of the lane's 16-byte slot in an accumulator-ordered plane.  f32 = first feature of the 32-tile.
+EG_D size_t acc_slot(int m, int f32, int jj, int hf, int K16) {
+    return ((((size_t)(m >> 5) * (size_t)K16 + (size_t)((f32 >> 4) + jj)) * 2 + (size_t)hf) << 8) + (size_t)((m & 31) << 3);
+}
+
 EG_D void split_bf16(float v, __bf16& hi, __bf16& lo) {
     hi = (__bf16)v;
     lo = (__bf16)(v - (float)hi);

@@ -61,6 +61,7 @@ static const int N_MODEL = 512;
 static int g_stagger = getenv("EGOEGO_STAGGER") ? atoi(getenv("EGOEGO_STAGGER")) : 0;           // perf experiment
 static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debug_trace_buffer
 static int g_chunk = getenv("EGOEGO_CHUNK") ? atoi(getenv("EGOEGO_CHUNK")) : 0;  // windows per denoiser pass (0 = whole batch)
+static int g_fuse_attn = getenv("EGOEGO_FUSE_ATTN") ? atoi(getenv("EGOEGO_FUSE_ATTN")) : 1;  // 0: separate qkv + attention kernels
 static int g_ablate = getenv("EGOEGO_ABLATE") ? atoi(getenv("EGOEGO_ABLATE")) : 0;  // perf-debug only
 
 struct Geometry {
@@ -114,6 +115,28 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
     w.V = (__bf16*)take(2 * w.qkv_plane * 2);
     w.O = (__bf16*)take(2 * w.o_plane * 2);
     w.total = off;
+}
+
+// ------------------------------------------------------------------------------------ fused QKV + attention
+// One workgroup per (window, head): the three 256-feature projection blocks Q_h, K_h, V_h of that window
+// (same main loop and epilogues as qkv_kernel), then attention over them.  The operands attention reads
+// were written microseconds earlier by the same CU, so they come back from L2 / Infinity Cache instead of
+// HBM, the attention launch disappears, and — since the two workgroups resident on a CU drift apart — one
+// workgroup's HBM/L2-bound attention phases overlap the other's MFMA-bound projections.
+// Valid when a window is exactly one token block of the QKV tile (Lp == 128).
+template <class CQK, class EQK, class CV, class EV, int KT, int NP>
+__global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperands g, EQK eqk, EV ev, AttnArgs a, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the H heads of a window share an XCD (and its L2)
+    const int bh = lid + a.bh0;
+    const int b = bh / H, h = bh - b * H;
+    GemmBody<CQK, EQK>::run(g, eqk, h, b, smem);
+    GemmBody<CQK, EQK>::run(g, eqk, H + h, b, smem);
+    GemmBody<CV, EV>::run(g, ev, 2 * H + h, b, smem);
+    // this workgroup's own Q/K/V stores must have reached L2 before its loads / LDS-DMAs of them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!(g.ablate & 4)) attn_body<KT, NP>(a, bh, 0, smem);  // ablate bit 2: skip attention (perf-debug)
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
@@ -225,28 +248,43 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     for (int li = 0; li < c->cfg.n_dec_layers; ++li) {
         const LayerDev& L = c->layers[li];
         const bool last_dbg = (li == io.stop_layer);
-        // --- Q, K, V projections (TM:71-73)
-        {
+        const bool dbg_qkv = last_dbg && (io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V);
+        EpiQK<NP> eqk{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
+        EpiV<NP> ev{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
+        AttnArgs aa{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L, w0 * H};
+        if (g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && !dbg_qkv) {
+            // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)
             ProfScope ps(c, EGOEGO_K_QKV, s);
-            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
-            EpiQK<NP> eqk{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
-            EpiV<NP> ev{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
-            auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
+            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0, g_ablate, g_stagger, g_trace};
+            auto kern = qkv_attn_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>, 4, NP>;
+            constexpr int smem = CfgA<NP>::SMEM_BYTES > 2 * 4 * NP * 4096 ? CfgA<NP>::SMEM_BYTES : 2 * 4 * NP * 4096;
             static bool once = false;
             if (!once) {
-                HIP_TRY(allow_smem(kern, CfgA<NP>::SMEM_BYTES));
+                HIP_TRY(allow_smem(kern, smem));
                 once = true;
             }
-            kern<<<dim3(go.nfb * go.ntb), dim3(CfgA<NP>::NT), CfgA<NP>::SMEM_BYTES, s>>>(go, eqk, ev, 2 * HD / BLK_A_F);
+            kern<<<dim3(nw * H), dim3(CfgA<NP>::NT), smem, s>>>(go, eqk, ev, aa, H);
             HIP_TRY(hipGetLastError());
-        }
-        if (last_dbg && (io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V))
-            return 0;
-        // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
-        {
-            ProfScope ps(c, EGOEGO_K_ATTN, s);
-            AttnArgs a{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L, w0 * H};
-            if (int r = launch_attn<NP>(a, g.KT, nw * H, s)) return r;
+        } else {
+            // --- Q, K, V projections (TM:71-73)
+            {
+                ProfScope ps(c, EGOEGO_K_QKV, s);
+                GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
+                auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
+                static bool once = false;
+                if (!once) {
+                    HIP_TRY(allow_smem(kern, CfgA<NP>::SMEM_BYTES));
+                    once = true;
+                }
+                kern<<<dim3(go.nfb * go.ntb), dim3(CfgA<NP>::NT), CfgA<NP>::SMEM_BYTES, s>>>(go, eqk, ev, 2 * HD / BLK_A_F);
+                HIP_TRY(hipGetLastError());
+            }
+            if (dbg_qkv) return 0;
+            // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
+            {
+                ProfScope ps(c, EGOEGO_K_ATTN, s);
+                if (int r = launch_attn<NP>(aa, g.KT, nw * H, s)) return r;
+            }
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_OUT) return 0;
         // --- fc + residual + LayerNorm (+ padding mask) (TM:92-93, 135)
@@ -402,10 +440,10 @@ static int dev_alloc(egoego_ctx* c, void** p, size_t bytes, bool zero, hipStream
 }
 
 static int pack_weight(const float* src, int R, int ncols, int ld, int c0, __bf16* dst, size_t plane, int K16, int r0,
-                       int k0, hipStream_t s) {
+                       int k0, hipStream_t s, int acc_order = 1) {
     const size_t n = (size_t)R * (ncols / 2);
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    k_pack_rows<<<blocks, 256, 0, s>>>(src, R, ncols, ld, c0, dst, plane, K16, r0, k0, 1);
+    k_pack_rows<<<blocks, 256, 0, s>>>(src, R, ncols, ld, c0, dst, plane, K16, r0, k0, 1, acc_order);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -432,8 +470,8 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
     int r;
     // embed: start_conv.weight (512, 2D, 1): input columns [0,D) -> k [0,D), [D,2D) -> k [DP, DP+D)
     if ((r = dev_alloc(c, (void**)&c->w_embed, (size_t)2 * N_MODEL * KE * 2, true, s))) return r;
-    if ((r = pack_weight(wt->start_conv_w, N_MODEL, D, 2 * D, 0, c->w_embed, (size_t)N_MODEL * KE, KE / 16, 0, 0, s))) return r;
-    if ((r = pack_weight(wt->start_conv_w, N_MODEL, D, 2 * D, D, c->w_embed, (size_t)N_MODEL * KE, KE / 16, 0, DP, s))) return r;
+    if ((r = pack_weight(wt->start_conv_w, N_MODEL, D, 2 * D, 0, c->w_embed, (size_t)N_MODEL * KE, KE / 16, 0, 0, s, 0))) return r;
+    if ((r = pack_weight(wt->start_conv_w, N_MODEL, D, 2 * D, D, c->w_embed, (size_t)N_MODEL * KE, KE / 16, 0, DP, s, 0))) return r;
     if ((r = copy_vec(c, &c->b_embed, wt->start_conv_b, N_MODEL, N_MODEL, s))) return r;
     const int pe_rows = c->cfg.max_timesteps + 1;
     if ((r = copy_vec(c, &c->pe, wt->position_vec, pe_rows * N_MODEL, pe_rows * N_MODEL, s))) return r;

@@ -329,23 +329,25 @@ struct EpiTiled {
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = f0 + i * 32 + 8 * g + 4 * hf;
-                const float4 b = *(const float4*)(bias + f);
+            for (int jj = 0; jj < 2; ++jj) {
+                const int fb = f0 + i * 32 + 16 * jj + 4 * hf;  // features fb..fb+3 and fb+8..fb+11
+                const float4 b0 = *(const float4*)(bias + fb);
+                const float4 b1 = *(const float4*)(bias + fb + 8);
 #pragma unroll
                 for (int j = 0; j < TT; ++j) {
                     const int m = t0 + j * 32 + col;
-                    float v[4] = {acc[i][j][4 * g + 0] + b.x, acc[i][j][4 * g + 1] + b.y,
-                                  acc[i][j][4 * g + 2] + b.z, acc[i][j][4 * g + 3] + b.w};
+                    float v[8] = {acc[i][j][8 * jj + 0] + b0.x, acc[i][j][8 * jj + 1] + b0.y, acc[i][j][8 * jj + 2] + b0.z,
+                                  acc[i][j][8 * jj + 3] + b0.w, acc[i][j][8 * jj + 4] + b1.x, acc[i][j][8 * jj + 5] + b1.y,
+                                  acc[i][j][8 * jj + 6] + b1.z, acc[i][j][8 * jj + 7] + b1.w};
                     if (RELU) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                        for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
                     }
-                    uint2 hi, lo;
-                    split4(v, hi, lo);
-                    const size_t idx = tiled_index(m, f, N16);
-                    *(uint2*)(out + idx) = hi;
-                    if (NP == 2) *(uint2*)(out + out_plane + idx) = lo;
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, N16);
+                    *(u32x4*)(out + idx) = hi;
+                    if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
                 }
             }
     }
@@ -379,16 +381,19 @@ struct EpiQK {
                 const float sc = which ? 1.0f : qscale;
                 const size_t blk0 = ((size_t)(b * H + h) * LT + lt) * 16;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = d0 + 8 * g + 4 * hf;
-                    const float4 bb = *(const float4*)(bias + fb + 8 * g + 4 * hf);
-                    float v[4] = {(acc[i][j][4 * g + 0] + bb.x) * sc, (acc[i][j][4 * g + 1] + bb.y) * sc,
-                                  (acc[i][j][4 * g + 2] + bb.z) * sc, (acc[i][j][4 * g + 3] + bb.w) * sc};
-                    uint2 hi, lo;
-                    split4(v, hi, lo);
-                    const size_t idx = (((blk0 + (d >> 4)) * 2 + ((d >> 3) & 1)) << 8) + col * 8 + 4 * hf;
-                    *(uint2*)(dst + idx) = hi;
-                    if (NP == 2) *(uint2*)(dst + plane + idx) = lo;
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float4 b0 = *(const float4*)(bias + fb + 16 * jj + 4 * hf);
+                    const float4 b1 = *(const float4*)(bias + fb + 16 * jj + 4 * hf + 8);
+                    float v[8] = {(acc[i][j][8 * jj + 0] + b0.x) * sc, (acc[i][j][8 * jj + 1] + b0.y) * sc,
+                                  (acc[i][j][8 * jj + 2] + b0.z) * sc, (acc[i][j][8 * jj + 3] + b0.w) * sc,
+                                  (acc[i][j][8 * jj + 4] + b1.x) * sc, (acc[i][j][8 * jj + 5] + b1.y) * sc,
+                                  (acc[i][j][8 * jj + 6] + b1.z) * sc, (acc[i][j][8 * jj + 7] + b1.w) * sc};
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    // d_k kept in accumulator order (common.h swap23): one 16-byte store per lane
+                    const size_t idx = (((blk0 + (size_t)((d0 >> 4) + jj)) * 2 + (size_t)hf) << 8) + col * 8;
+                    *(u32x4*)(dst + idx) = hi;
+                    if (NP == 2) *(u32x4*)(dst + plane + idx) = lo;
                 }
             }
         }
@@ -471,23 +476,25 @@ struct EpiResLN {
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f = f0 + i * 32 + 8 * g + 4 * hf;
-                    const float4 b = *(const float4*)(bias + f);
-                    const size_t idx = tiled_index(m, f, 32);
-                    float r[4];
-                    const uint2 rh = *(const uint2*)(res + idx);
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int fb = f0 + i * 32 + 16 * jj + 4 * hf;
+                    const float4 b0 = *(const float4*)(bias + fb);
+                    const float4 b1 = *(const float4*)(bias + fb + 8);
+                    const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
+                    float r[8];
+                    const u32x4 rh = *(const u32x4*)(res + idx);
                     if (NP == 2) {
-                        const uint2 rl = *(const uint2*)(res + res_plane + idx);
-                        unpack4(rh, rl, r);
+                        const u32x4 rl = *(const u32x4*)(res + res_plane + idx);
+                        unpack8(rh, rl, r);
                     } else {
-                        unpack4_hi(rh, r);
+                        unpack8_hi(rh, r);
                     }
-                    acc[i][j][4 * g + 0] += b.x + r[0];
-                    acc[i][j][4 * g + 1] += b.y + r[1];
-                    acc[i][j][4 * g + 2] += b.z + r[2];
-                    acc[i][j][4 * g + 3] += b.w + r[3];
-                    s1 += (acc[i][j][4 * g + 0] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
+                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        acc[i][j][8 * jj + c] += bb[c] + r[c];
+                        s1 += acc[i][j][8 * jj + c];
+                    }
                 }
             s1 += __shfl_xor(s1, 32);
             if (hf == 0) red1[slot + wf * BT] = s1;
@@ -516,20 +523,20 @@ struct EpiResLN {
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f = f0 + i * 32 + 8 * g + 4 * hf;
-                    const float4 ga = *(const float4*)(gamma + f);
-                    const float4 be = *(const float4*)(beta + f);
-                    float v[4];
-                    v[0] = ((acc[i][j][4 * g + 0] - mean) * rstd * ga.x + be.x) * mk;
-                    v[1] = ((acc[i][j][4 * g + 1] - mean) * rstd * ga.y + be.y) * mk;
-                    v[2] = ((acc[i][j][4 * g + 2] - mean) * rstd * ga.z + be.z) * mk;
-                    v[3] = ((acc[i][j][4 * g + 3] - mean) * rstd * ga.w + be.w) * mk;
-                    uint2 hi, lo;
-                    split4(v, hi, lo);
-                    const size_t idx = tiled_index(m, f, 32);
-                    *(uint2*)(out + idx) = hi;
-                    if (NP == 2) *(uint2*)(out + out_plane + idx) = lo;
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int fb = f0 + i * 32 + 16 * jj + 4 * hf;
+                    const float4 g0 = *(const float4*)(gamma + fb), g1 = *(const float4*)(gamma + fb + 8);
+                    const float4 e0 = *(const float4*)(beta + fb), e1 = *(const float4*)(beta + fb + 8);
+                    const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                    const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = ((acc[i][j][8 * jj + c] - mean) * rstd * ga[c] + be[c]) * mk;
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
+                    *(u32x4*)(out + idx) = hi;
+                    if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -560,25 +567,26 @@ struct EpiEmbed {
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f = f0 + i * 32 + 8 * g + 4 * hf;
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int fb = f0 + i * 32 + 16 * jj + 4 * hf;
+                    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     if (kind == 1) {
-                        const float4 t4 = *(const float4*)(trow + f);
-                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                        const float4 t0v = *(const float4*)(trow + fb), t1v = *(const float4*)(trow + fb + 8);
+                        v[0] = t0v.x; v[1] = t0v.y; v[2] = t0v.z; v[3] = t0v.w;
+                        v[4] = t1v.x; v[5] = t1v.y; v[6] = t1v.z; v[7] = t1v.w;
                     } else if (kind == 2) {
-                        const float4 b4 = *(const float4*)(bias + f);
-                        const float4 p4 = *(const float4*)(prow + f);
-                        v[0] = (acc[i][j][4 * g + 0] + b4.x) + p4.x;
-                        v[1] = (acc[i][j][4 * g + 1] + b4.y) + p4.y;
-                        v[2] = (acc[i][j][4 * g + 2] + b4.z) + p4.z;
-                        v[3] = (acc[i][j][4 * g + 3] + b4.w) + p4.w;
+                        const float4 b0 = *(const float4*)(bias + fb), b1 = *(const float4*)(bias + fb + 8);
+                        const float4 p0 = *(const float4*)(prow + fb), p1 = *(const float4*)(prow + fb + 8);
+                        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                        const float pp[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = (acc[i][j][8 * jj + c] + bb[c]) + pp[c];
                     }
-                    uint2 hi, lo;
-                    split4(v, hi, lo);
-                    const size_t idx = tiled_index(m, f, 32);
-                    *(uint2*)(out + idx) = hi;
-                    if (NP == 2) *(uint2*)(out + out_plane + idx) = lo;
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
+                    *(u32x4*)(out + idx) = hi;
+                    if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
                 }
         }
     }

@@ -7,7 +7,7 @@
 // (row r0 + r, column k0 + c) and scaled by `scale`.  The destination is pre-zeroed by the caller,
 // so padding rows/columns stay zero.  One thread per PAIR of columns (ncols must be even).
 __global__ void k_pack_rows(const float* __restrict__ src, int R, int ncols, int ld, int c0, __bf16* dst,
-                            size_t dst_plane, int K16, int r0, int k0, int write_lo) {
+                            size_t dst_plane, int K16, int r0, int k0, int write_lo, int acc_order) {
     const int half = ncols >> 1;
     const size_t n = (size_t)R * half;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -16,7 +16,9 @@ __global__ void k_pack_rows(const float* __restrict__ src, int R, int ncols, int
         __bf16 h0, l0, h1, l1;
         split_bf16(v.x, h0, l0);
         split_bf16(v.y, h1, l1);
-        const size_t idx = tiled_index(r0 + r, k0 + c, K16);
+        // acc_order: the K axis of these weights contracts with an activation kept in accumulator order
+        // (common.h swap23); the pair (c, c+1) stays adjacent under that permutation
+        const size_t idx = acc_order ? tiled_index_acc(r0 + r, k0 + c, K16) : tiled_index(r0 + r, k0 + c, K16);
         bf16x2 hh = {h0, h1}, ll = {l0, l1};
         *(bf16x2*)(dst + idx) = hh;
         if (write_lo) *(bf16x2*)(dst + dst_plane + idx) = ll;
@@ -139,7 +141,7 @@ __global__ void k_unpack_tiled(const __bf16* __restrict__ src, size_t plane, int
         const int f = (int)(i % N);
         const size_t bl = i / N;
         const int l = (int)(bl % L), b = (int)(bl / L);
-        const size_t idx = tiled_index(b * Lp + l, f, N >> 4);
+        const size_t idx = tiled_index_acc(b * Lp + l, f, N >> 4);
         float v = (float)src[idx];
         if (use_lo) v += (float)src[plane + idx];
         out[i] = v;
@@ -155,7 +157,7 @@ __global__ void k_unpack_qk(const __bf16* __restrict__ src, size_t plane, int H,
         const size_t r = i >> 8;
         const int l = (int)(r % L);
         const size_t bh = r / L;
-        const size_t idx = bh * (size_t)Lp * 256 + tiled_index(l, d, 16);
+        const size_t idx = bh * (size_t)Lp * 256 + tiled_index_acc(l, d, 16);
         float v = (float)src[idx];
         if (use_lo) v += (float)src[plane + idx];
         out[i] = v;

@@ -72,6 +72,51 @@ def test_swapped_gemm_epilogue_addresses():
             assert abs(out[tiled_index(m, f, N // 16)] - Y[m, f]) < 1e-9
 
 
+def swap23(k):
+    return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)
+
+
+def test_accumulator_order_chain_of_two_gemms():
+    """Epilogues store activations in 'accumulator order' (feature bits 2 and 3 swapped inside each group of
+    16) with ONE 16-byte slot per lane per (tile, jj); the consumer's weights are packed with the same
+    permutation along K.  Chain two emulated GEMMs and compare with the plain matmul."""
+    assert all(swap23(swap23(k)) == k for k in range(64))
+    rng = np.random.default_rng(3)
+    N1, N2, M, K = 32, 32, 32, 32
+    W1, W2, X = rng.standard_normal((N1, K)), rng.standard_normal((N2, N1)), rng.standard_normal((M, K))
+    w1p, xp = np.zeros(N1 * K), np.zeros(M * K)
+    for r in range(32):
+        for k in range(K):
+            w1p[tiled_index(r, k, K // 16)] = W1[r, k]       # first GEMM consumes a natural-order operand
+            xp[tiled_index(r, k, K // 16)] = X[r, k]
+    acc = np.zeros((64, 16))
+    for ks in range(K // 16):
+        acc = mfma_32x32x16(frag_from_tiled(w1p, 0, ks, K // 16), frag_from_tiled(xp, 0, ks, K // 16), acc)
+    # epilogue (gemm.h acc_slot): lane (col, hf), jj: regs 8jj..8jj+7 -> 8 contiguous elements of block ks16 = jj, half hf
+    yp = np.zeros(M * N1)
+    for l in range(64):
+        hf, col = l >> 5, l & 31
+        for jj in range(2):
+            base = ((0 * (N1 // 16) + jj) * 2 + hf) * 256 + col * 8
+            yp[base:base + 8] = acc[l, 8 * jj:8 * jj + 8]
+    Y = X @ W1.T
+    for m in range(M):
+        for f in range(N1):
+            assert abs(yp[tiled_index(m, swap23(f), N1 // 16)] - Y[m, f]) < 1e-9
+    # second GEMM: weights packed in accumulator order along K
+    w2p = np.zeros(N2 * N1)
+    for r in range(N2):
+        for k in range(N1):
+            w2p[tiled_index(r, swap23(k), N1 // 16)] = W2[r, k]
+    acc2 = np.zeros((64, 16))
+    for ks in range(N1 // 16):
+        acc2 = mfma_32x32x16(frag_from_tiled(w2p, 0, ks, N1 // 16), frag_from_tiled(yp, 0, ks, N1 // 16), acc2)
+    Z = Y @ W2.T
+    for l in range(64):
+        for r in range(16):
+            assert abs(acc2[l, r] - Z[l & 31, (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]) < 1e-9
+
+
 def test_v_key_permutation_matches_softmax_accumulator():
     """S^T accumulator regs 8jj..8jj+7 of a lane, used verbatim as the PV B-fragment, pair with the V^T
     fragment written by EpiV: slot (hf, e) <-> key 16*kg + 8*(e>>2) + 4*hf + (e&3)."""
