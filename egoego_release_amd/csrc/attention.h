@@ -33,8 +33,12 @@ struct AttnArgs {
     int bh0;   // first (batch, head) pair of this launch (window-chunked launches)
 };
 
-template <int KT, int NP>
-__device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock, char* smem) {
+// QREG: the Q fragments are not read from global memory but handed over in registers by the caller
+// (the fused kernel computes the Q projection last and keeps it): qreg_h/qreg_l[2*i + jj] is the B-operand
+// fragment of k-step 2*i + jj in accumulator order, the order in which K is stored.
+template <int KT, int NP, bool QREG = false>
+__device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock, char* smem,
+                                          const bf16x8* qreg_h = nullptr, const bf16x8* qreg_l = nullptr) {
     constexpr int NCH = KT * NP;                  // 16-byte chunks per thread per phase
     constexpr int STAGE_BYTES = KT * NP * 4096;   // K chunk: KT tiles x NP planes x 4 k-steps x 1 KiB
     constexpr int Lp = KT * 32;
@@ -80,10 +84,12 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
                                              (__attribute__((address_space(3))) void*)(dst + (size_t)j * 4096), 16, 0, 0);
     };
     dma_phase(0, 0);
+    if constexpr (!QREG) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) qb[0][ks][p] = *q_src(0, ks, p);
+            for (int p = 0; p < NP; ++p) qb[0][ks][p] = *q_src(0, ks, p);
+    }
 
     auto phase = [&](auto PHC) {
         constexpr int ph = decltype(PHC)::value;
@@ -94,7 +100,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if constexpr (ph < 7) dma_phase(ph + 1, buf ^ 1);
-        if constexpr (ph < 3) {
+        if constexpr (ph < 3 && !QREG) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -106,8 +112,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
             // S^T += K_chunk x Q_chunk^T
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 qh = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][0]);
-                const bf16x8 ql = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][NP - 1]);
+                bf16x8 qh, ql;
+                if constexpr (QREG) {
+                    qh = qreg_h[4 * (ph < 4 ? ph : 0) + ks];
+                    ql = qreg_l[4 * (ph < 4 ? ph : 0) + ks];
+                } else {
+                    qh = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][0]);
+                    ql = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][NP - 1]);
+                }
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     const bf16x8 kh = *(const bf16x8*)(sb + ((0 * KT + kt) * 4 + ks) * 1024);

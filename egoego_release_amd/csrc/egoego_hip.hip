@@ -124,19 +124,44 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
 // HBM, the attention launch disappears, and — since the two workgroups resident on a CU drift apart — one
 // workgroup's HBM/L2-bound attention phases overlap the other's MFMA-bound projections.
 // Valid when a window is exactly one token block of the QKV tile (Lp == 128).
-template <class CQK, class EQK, class CV, class EV, int KT, int NP>
+template <class CQK, class EQK, class CV, class EV, class CQ, int KT, int NP>
 __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperands g, EQK eqk, EV ev, AttnArgs a, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the H heads of a window share an XCD (and its L2)
     const int bh = lid + a.bh0;
     const int b = bh / H, h = bh - b * H;
-    GemmBody<CQK, EQK>::run(g, eqk, h, b, smem);
-    GemmBody<CQK, EQK>::run(g, eqk, H + h, b, smem);
-    GemmBody<CV, EV>::run(g, ev, 2 * H + h, b, smem);
-    // this workgroup's own Q/K/V stores must have reached L2 before its loads / LDS-DMAs of them
+    GemmBody<CQK, EQK>::run(g, eqk, H + h, b, smem);     // K_h -> global (accumulator order along d_k)
+    GemmBody<CV, EV>::run(g, ev, 2 * H + h, b, smem);    // V_h -> global (transposed, key-permuted)
+    // Q_h last, with waves laid out 1(f) x 4(t): wave w ends up holding all 256 d_k of its 32 queries.
+    // It never goes to memory: bias, 1/sqrt(d_k), split-bf16 — and the accumulator registers 8jj..8jj+7 of
+    // feature tile i ARE the B-operand fragment of k-step 2i+jj in the order K was stored in.
+    static_assert(CQ::FT == 8 && CQ::TT == 1 && CQ::NWF == 1 && CQ::NWT == 4, "Q layout: 256 features x 32 queries per wave");
+    bf16x8 qh[16], ql[16];
+    {
+        f32x16 acc[CQ::FT][CQ::TT];
+        GemmBody<CQ, EQK>::mainloop(g, h, b, smem, acc);
+        const int lane = threadIdx.x & 63, hf = lane >> 5;
+        const float* bias = eqk.bias + h * 256;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float4 b0 = *(const float4*)(bias + 32 * i + 16 * jj + 4 * hf);
+                const float4 b1 = *(const float4*)(bias + 32 * i + 16 * jj + 4 * hf + 8);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (acc[i][0][8 * jj + e] + bb[e]) * eqk.qscale;
+                    const __bf16 x = (__bf16)v;
+                    qh[2 * i + jj][e] = x;
+                    ql[2 * i + jj][e] = (__bf16)(v - (float)x);
+                }
+            }
+    }
+    // this workgroup's own K/V stores must have reached L2 before its LDS-DMAs of them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!(g.ablate & 4)) attn_body<KT, NP>(a, bh, 0, smem);  // ablate bit 2: skip attention (perf-debug)
+    if (!(g.ablate & 4)) attn_body<KT, NP, true>(a, bh, 0, smem, qh, ql);  // ablate bit 2: skip attention (perf-debug)
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
@@ -178,6 +203,7 @@ template <int NP> using CfgA = GemmCfg<4, 2, 2, 2, 1, NP, false, 2, 3>;
 template <int NP> using CfgAV = GemmCfg<4, 2, 2, 2, 1, NP, true, 2, 3>;
 template <int NP> using CfgB = GemmCfg<4, 2, 4, 2, (NP == 2 ? 1 : 2), NP, false, 1, 3>;
 template <int NP> using CfgC = GemmCfg<2, 2, 4, 2, 2, NP, false>;
+template <int NP> using CfgQ = GemmCfg<8, 1, 1, 4, 1, NP, false, 2, 3>;  // fused kernel's Q projection: 256f x 32t per wave
 static const int BLK_A_F = 256, BLK_A_T = 128, BLK_B_T = 128;
 
 template <class C, class Epi>
@@ -256,7 +282,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)
             ProfScope ps(c, EGOEGO_K_QKV, s);
             GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0, g_ablate, g_stagger, g_trace};
-            auto kern = qkv_attn_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>, 4, NP>;
+            auto kern = qkv_attn_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>, CfgQ<NP>, 4, NP>;
             constexpr int smem = CfgA<NP>::SMEM_BYTES > 2 * 4 * NP * 4096 ? CfgA<NP>::SMEM_BYTES : 2 * 4 * NP * 4096;
             static bool once = false;
             if (!once) {

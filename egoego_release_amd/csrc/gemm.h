@@ -78,7 +78,8 @@ struct GemmCfg {
 
 template <class C, class Epi>
 struct GemmBody {
-    static __device__ void run(const GemmOperands& g, const Epi& epi, int fblk, int tblk, char* smem) {
+    // main loop only: on return acc[ft][tt] holds the pre-epilogue sums of this wave's tile
+    static __device__ void mainloop(const GemmOperands& g, int fblk, int tblk, char* smem, f32x16 (&acc)[C::FT][C::TT]) {
         constexpr int FT = C::FT, TT = C::TT, KS = C::KS, NP = C::NP, WT = C::WT, AT = C::AT, NW = C::NW;
         constexpr int NCH = C::NCH;
         const int wave = wave_id_uniform();
@@ -109,7 +110,6 @@ struct GemmBody {
             gp[j] = base + lane;
         }
 
-        f32x16 acc[FT][TT];
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -257,18 +257,25 @@ struct GemmBody {
             mfmas(a0, w1, 1, false, 0, 0, 0);
         }
         __syncthreads();
-
-        const int f0 = (fblk * WT + wf * FT) * 32;
-        const int t0 = (tblk * AT + wt * TT) * 32;
         if (g.trace && threadIdx.x == 0) {
             g.trace[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
             g.trace[65536 + (size_t)blockIdx.x * 2 + 1] = __builtin_readcyclecounter();
         }
+    }
+
+    static __device__ void run(const GemmOperands& g, const Epi& epi, int fblk, int tblk, char* smem) {
+        f32x16 acc[C::FT][C::TT];
+        mainloop(g, fblk, tblk, smem, acc);
+        const int wave = wave_id_uniform();
+        const int lane = threadIdx.x & 63;
+        const int wf = wave % C::NWF, wt = wave / C::NWF;
+        const int f0 = (fblk * C::WT + wf * C::FT) * 32;
+        const int t0 = (tblk * C::AT + wt * C::TT) * 32;
         if (g.ablate & 2) {
-            if (acc[0][0][0] == 123.456f) *(float*)smem = acc[FT - 1][TT - 1][7];  // keep the MFMAs alive
+            if (acc[0][0][0] == 123.456f) *(float*)smem = acc[C::FT - 1][C::TT - 1][7];  // keep the MFMAs alive
             return;
         }
-        epi.template run<FT, TT>(acc, f0, t0, lane, wf, wt, smem);
+        epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
         if (g.trace) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (threadIdx.x == 0) g.trace[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
