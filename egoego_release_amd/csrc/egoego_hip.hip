@@ -130,8 +130,12 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperan
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the H heads of a window share an XCD (and its L2)
     const int bh = lid + a.bh0;
     const int b = bh / H, h = bh - b * H;
+    unsigned long long* tr = g.trace ? g.trace + 131072 + (size_t)blockIdx.x * 8 : nullptr;  // perf-debug marks
+    if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
     GemmBody<CQK, EQK>::run(g, eqk, H + h, b, smem);     // K_h -> global (accumulator order along d_k)
+    if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
     GemmBody<CV, EV>::run(g, ev, 2 * H + h, b, smem);    // V_h -> global (transposed, key-permuted)
+    if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
     // Q_h last, with waves laid out 1(f) x 4(t): wave w ends up holding all 256 d_k of its 32 queries.
     // It never goes to memory: bias, 1/sqrt(d_k), split-bf16 — and the accumulator registers 8jj..8jj+7 of
     // feature tile i ARE the B-operand fragment of k-step 2i+jj in the order K was stored in.
@@ -161,7 +165,12 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperan
     // this workgroup's own K/V stores must have reached L2 before its LDS-DMAs of them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
     if (!(g.ablate & 4)) attn_body<KT, NP, true>(a, bh, 0, smem, qh, ql);  // ablate bit 2: skip attention (perf-debug)
+    if (tr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) tr[4] = wall_clock64();
+    }
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
