@@ -240,3 +240,25 @@ def rotation_6d_to_matrix(d6):
     b2 = F.normalize(b2, dim=-1)
     b3 = torch.cross(b1, b2, dim=-1)
     return torch.stack((b1, b2, b3), dim=-2)
+
+
+# --------------------------------------------------------------------------- DDIM (NOT in the reference)
+def ddim_loop(sd, sched, x, x_cond, timesteps, objective="pred_x0"):
+    """Deterministic DDIM (eta = 0; Song et al. 2021 eq. 12) on a descending list of timesteps, with the
+    reference's x0 clamp.  The reference has no DDIM sampler, so this restates the
+    published update rule, not reference code; it is the checker for egoego_ddim_loop only."""
+    abar = sched["alphas_cumprod"]
+    b = x.shape[0]
+    for i, t in enumerate(timesteps):
+        tt = torch.full((b,), int(t), dtype=torch.long)
+        out = denoise(sd, torch.cat((x, x_cond), dim=-1), tt)
+        if objective == "pred_x0":
+            x0 = out
+        else:
+            x0 = sched["sqrt_recip_alphas_cumprod"][t] * x - sched["sqrt_recipm1_alphas_cumprod"][t] * out
+        x0 = x0.clamp(-1.0, 1.0)
+        a_t = abar[t]
+        a_prev = abar[timesteps[i + 1]] if i + 1 < len(timesteps) else torch.tensor(1.0)
+        eps = (x - a_t.sqrt() * x0) / (1 - a_t).clamp(min=1e-20).sqrt()
+        x = a_prev.sqrt() * x0 + (1 - a_prev).clamp(min=0).sqrt() * eps
+    return x

@@ -212,3 +212,22 @@ def test_error_paths():
     m.objective = "pred_v"
     with pytest.raises(ValueError, match="unknown objective"):
         m.hip_engine()
+
+
+def test_ddim_against_oracle_restatement():
+    """BASELINE config 4's sampler.  No reference oracle exists for DDIM (the reference only has the ancestral
+    chain): the check is against oracle.ddim_loop, a restatement of the published eta=0 update."""
+    cfg, sd, m = _model()
+    sched = O.make_schedule(1000)
+    B, T = 2, 120
+    xs, cm = make_head_windows(B, T, seed=8)
+    nz = _ref_noise(xs.shape, 1, seed=4)
+    y = m.ddim_sample(xs.cuda(), cm.cuda(), n_steps=12, noise=nz).cpu()
+    ts = sorted({int(round(v)) for v in np.linspace(0, 999, 12)}, reverse=True)
+    xc = xs * (1 - cm) + cm * nz["cond"]
+    with torch.no_grad():
+        want = O.ddim_loop(sd, sched, nz["x_T"].clone(), xc, ts)
+    assert (y - want).abs().max().item() < POSE_TOL
+    assert y.abs().max().item() <= 1.0 + 1e-6  # last step lands on clamp(x0)
+    with pytest.raises(_lib.EgoEgoHipError, match="strictly descending"):
+        m.hip_engine().ddim_loop_(xs.cuda(), xs.cuda(), [5, 7])
