@@ -231,3 +231,38 @@ def test_ddim_against_oracle_restatement():
     assert y.abs().max().item() <= 1.0 + 1e-6  # last step lands on clamp(x0)
     with pytest.raises(_lib.EgoEgoHipError, match="strictly descending"):
         m.hip_engine().ddim_loop_(xs.cuda(), xs.cuda(), [5, 7])
+
+
+@pytest.mark.parametrize("B,T,n_head,n_layers", [(1, 1, 4, 4), (3, 2, 4, 4), (5, 31, 4, 4), (3, 63, 4, 4), (2, 127, 4, 4),
+                                                  (2, 128, 4, 4), (1, 223, 4, 4), (2, 50, 2, 1), (2, 120, 8, 2)])
+def test_shape_edge_cases_against_oracle(B, T, n_head, n_layers):
+    """Minimum window (T=1), every key-tile boundary (L = 32/64/128/129), the maximum supported window
+    (T=223), odd batches, and other head / layer counts than the shipped checkpoint's."""
+    cfg = ModelConfig(max_timesteps=T + 1, n_head=n_head, n_dec_layers=n_layers)
+    sd = make_weights(cfg, 3)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(100 * T + B)
+    x_all = torch.randn(B, T, 396, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        want = O.denoise(sd, x_all, t, n_head=n_head)
+    got = m.denoise(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda()).cpu()
+    assert (got - want).abs().max().item() < POSE_TOL
+    # one posterior step on top, ragged per-row timesteps included
+    noise = torch.randn(B, T, 198, generator=g)
+    want = O.p_sample(sd, O.make_schedule(1000), x_all[..., :198], t, x_all[..., 198:], noise, n_head=n_head)
+    got = m.p_sample(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda(), noise=noise.cuda()).cpu()
+    assert (got - want).abs().max().item() < POSE_TOL
+
+
+def test_unsupported_shapes_fail_loudly():
+    with pytest.raises(_lib.EgoEgoHipError, match="d_model"):
+        m = CondGaussianDiffusion(198, 256, 4, 4, 256, 256, 121, 198, objective="pred_x0").cuda()
+        m.hip_engine()
+    cfg = ModelConfig(max_timesteps=300)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs()).cuda()
+    x = torch.zeros(1, 224, 198, device="cuda")
+    with pytest.raises(_lib.EgoEgoHipError, match="not supported"):
+        m.denoise(x, torch.zeros(1, dtype=torch.long, device="cuda"), x)

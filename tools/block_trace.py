@@ -27,13 +27,16 @@ torch.cuda.synchronize()
 buf = torch.zeros(65536 + 2 * 16384, dtype=torch.int64, device="cuda")
 lib.egoego_debug_trace_buffer.argtypes = [C.c_void_p]
 lib.egoego_debug_trace_buffer(C.c_void_p(buf.data_ptr()))
-stage = {"ffn1": "ffn_hidden", "qkv": "q", "fc_ln": "attn_ln", "ffn2_ln": "out"}[which]
-eng.debug_stage(x, xc, t, 0, stage)   # the LAST gemm launched is the one named by `which`
+stage = {"ffn1": "ffn_hidden", "qkv": "q", "fc_ln": "attn_ln", "ffn2_ln": "out", "embed": "embed"}.get(which)
+if which == "out":
+    eng.denoise(x, xc, t)
+else:
+    eng.debug_stage(x, xc, t, 0, stage)   # the LAST gemm launched is the one named by `which`
 torch.cuda.synchronize()
 lib.egoego_debug_trace_buffer(None)
 cyc = buf.cpu()[65536:].view(-1, 2)
 tr = buf.cpu()[:65536].view(-1, 4)
-n = {"ffn1": 512, "qkv": 3072, "fc_ln": 256, "ffn2_ln": 256}[which]  # blocks of the LAST launch (earlier launches leave stale rows)
+n = {"ffn1": 512, "qkv": 3072, "fc_ln": 256, "ffn2_ln": 256, "embed": 512, "out": 256}[which]  # blocks of the LAST launch (earlier launches leave stale rows)
 tr = tr[:n]
 t0 = int(tr[:, 0].min())
 print(f"{which}: {n} blocks; kernel span {(int(tr[:, 2].max()) - t0) / 100:.1f} us")
