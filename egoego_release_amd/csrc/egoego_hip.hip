@@ -287,7 +287,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         EpiQK<NP> eqk{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
         EpiV<NP> ev{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
         AttnArgs aa{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L, w0 * H};
-        if (g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && !dbg_qkv) {
+        // the fused kernel has one workgroup per (window, head): below ~one workgroup per CU the unfused pair
+        // (12 projection blocks per window) spreads the same work over more CUs
+        if (g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && !dbg_qkv && nw * H >= 192) {
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)
             ProfScope ps(c, EGOEGO_K_QKV, s);
             GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0, g_ablate, g_stagger, g_trace};
