@@ -212,6 +212,8 @@ template <int NP> using CfgA = GemmCfg<4, 2, 2, 2, 1, NP, false, 2, 3>;
 template <int NP> using CfgAV = GemmCfg<4, 2, 2, 2, 1, NP, true, 2, 3>;
 template <int NP> using CfgB = GemmCfg<4, 2, 4, 2, (NP == 2 ? 1 : 2), NP, false, 1, 3>;
 template <int NP> using CfgC = GemmCfg<2, 2, 4, 2, 2, NP, false>;
+// B for small batches: 512 x 64, 4 waves, 2-stage ring, two workgroups per CU — twice the blocks of B
+template <int NP> using CfgBs = GemmCfg<4, 2, 4, 1, (NP == 2 ? 1 : 2), NP, false, 2, 2>;
 template <int NP> using CfgQ = GemmCfg<8, 1, 1, 4, 1, NP, false, 2, 3>;  // fused kernel's Q projection: 256f x 32t per wave
 static const int BLK_A_F = 256, BLK_A_T = 128, BLK_B_T = 128;
 
@@ -272,6 +274,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     if (w0 + nw >= g.B) rows = g.Mp - row0;  // the last chunk also carries the rows that pad Mp to the block size
     const int tb_a = rows / BLK_A_T, tb_b = rows / BLK_B_T, tb_c = rows / CfgC<NP>::BT;
     const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
+    const bool small_ln = tb_b < 200;  // fewer 128-token LayerNorm blocks than CUs: use the 64-token tile
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
@@ -327,9 +330,15 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // --- fc + residual + LayerNorm (+ padding mask) (TM:92-93, 135)
         {
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
-            GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
-            EpiResLN<NP, 4, 128> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
-            if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+            if (small_ln) {
+                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 64, row0 / 64, g_ablate, g_stagger, g_trace};
+                EpiResLN<NP, 4, 64> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+                if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
+            } else {
+                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
+                EpiResLN<NP, 4, 128> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+                if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+            }
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_LN) return 0;
         // --- FFN conv 1 + ReLU (TM:111)
@@ -343,9 +352,15 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // --- FFN conv 2 + residual + LayerNorm (+ padding mask) (TM:111-114, 139)
         {
             ProfScope ps(c, EGOEGO_K_FFN2_LN, s);
-            GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
-            EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
-            if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+            if (small_ln) {
+                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64, g_ablate, g_stagger, g_trace};
+                EpiResLN<NP, 4, 64> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
+                if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
+            } else {
+                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
+                EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
+                if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+            }
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_LAYER_OUT) return 0;
     }
