@@ -43,3 +43,14 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU or PyTorch fallback" in str(e)
     else:
         raise AssertionError("load() must raise when the .so is absent")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under egoego_release_amd/ (nor the C sources) may reference it."""
+    pkg = os.path.join(ROOT, "egoego_release_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+                assert "egoego_oracle" not in src and "harness_oracle" not in src.replace("oracle/harness_oracle.py", ""), f
