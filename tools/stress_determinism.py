@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Race screen: long chains at full size must be bit-identical run to run (any LDS-DMA / barrier hazard shows
+up as nondeterminism), for several shapes and both precisions."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from egoego_release_amd import ModelConfig, make_weights, _lib
+from egoego_release_amd.model import CondGaussianDiffusion
+
+bad = 0
+for (B, T, prec, steps) in ((256, 120, 3, 150), (64, 120, 3, 150), (7, 120, 3, 100), (256, 196, 3, 40), (96, 30, 3, 100), (256, 120, 1, 100)):
+    cfg = ModelConfig(max_timesteps=T + 1)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(make_weights(cfg, 0), strict=False)
+    m.hip_precision = prec
+    m = m.cuda()
+    eng = m.hip_engine()
+    g = torch.Generator().manual_seed(B + T)
+    x0 = torch.randn(B, T, 198, generator=g).cuda()
+    xc = torch.randn(B, T, 198, generator=g).cuda()
+    outs = []
+    for rep in range(3):
+        x = x0.clone()
+        eng.sample_loop_(x, xc, 999, steps, noise_mode=_lib.NOISE_PHILOX, seed=5)
+        torch.cuda.synchronize()
+        outs.append(x)
+    same = all(torch.equal(outs[0], o) for o in outs[1:])
+    finite = bool(torch.isfinite(outs[0]).all())
+    print(f"B={B} T={T} prec={prec} steps={steps}: bit-identical x3 = {same}, finite = {finite}", flush=True)
+    bad += (not same) or (not finite)
+    del m, eng
+sys.exit(1 if bad else 0)
