@@ -99,13 +99,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    backend = os.environ.get("EGOEGO_DIST_BACKEND", "nccl")  # "gloo" lets two ranks share one GPU (1-GPU test of this path)
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from egoego_release_amd import ModelConfig, make_weights, make_head_windows
     from egoego_release_amd.model import CondGaussianDiffusion
