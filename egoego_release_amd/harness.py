@@ -208,3 +208,33 @@ def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None
     jpos, jquat = head_pose[:, :, :3], head_pose[:, :, 3:]
     data = torch.zeros(head_pose.shape[0], head_pose.shape[1], 198, device=head_pose.device)
     return sample_sliding_window_w_canonical(model, ds, jpos, jquat, data, prep_head_condition_mask(data), noise=noise)
+
+
+# ------------------------------------------------------------------------------------------ checkpoints
+def build_stage2_model(window=120, d_model=512, n_head=4, n_dec_layers=4, d_k=256, d_v=256, repr_dim=22 * 3 + 22 * 6,
+                       device=None):
+    """The model `get_trainer()` builds (trainer_amass_cond_motion_diffusion.py:458-475): pred_x0, l1, 1000 cosine
+    steps, max_timesteps = window + 1."""
+    from .model import CondGaussianDiffusion
+    m = CondGaussianDiffusion(d_feats=repr_dim, d_model=d_model, n_head=n_head, n_dec_layers=n_dec_layers, d_k=d_k, d_v=d_v,
+                              max_timesteps=window + 1, out_dim=repr_dim, timesteps=1000, objective="pred_x0",
+                              loss_type="l1")
+    return m.to(device) if device is not None else m
+
+
+def load_stage2_checkpoint(path_or_dict, model=None, use_ema=True, device=None, **model_kw):
+    """Load a reference checkpoint — {'step', 'model', 'ema', 'scaler'} as written by Trainer.save
+    (trainer:99-106) — into the HIP-backed module.  Inference in the reference always goes through
+    `trainer.ema.ema_model` (trainer:243,263,273), so by default the EMA weights are taken: ema-pytorch stores them
+    under the 'ema_model.' prefix (next to 'online_model.*', 'initted', 'step').  Like the reference
+    (`strict=False`, trainer:120-121) unknown keys are ignored; missing ones are reported."""
+    data = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, (str, bytes)) or hasattr(path_or_dict, "read") else path_or_dict
+    if model is None:
+        model = build_stage2_model(device=device, **model_kw)
+    sd = None
+    if use_ema and "ema" in data:
+        sd = {k[len("ema_model."):]: v for k, v in data["ema"].items() if k.startswith("ema_model.")}
+    if not sd:
+        sd = data["model"] if "model" in data else data
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    return model, {"step": data.get("step"), "missing": list(missing), "unexpected": list(unexpected)}

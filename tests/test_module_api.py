@@ -75,3 +75,23 @@ def test_training_forward_matches_oracle():
     assert torch.isfinite(loss)
     loss.backward()
     assert m.denoise_fn.linear_out.weight.grad is not None
+
+
+def test_reference_checkpoint_format_loads(tmp_path):
+    """A file in the reference's checkpoint layout (trainer:99-106; EMA weights under 'ema_model.') loads into the
+    HIP-backed module; the EMA copy is the one used for inference."""
+    from egoego_release_amd import harness
+    cfg, m, sd = _model()
+    full = m.state_dict()
+    ema = {"ema_model." + k: (v + 1.0 if k.endswith("linear_out.bias") else v.clone()) for k, v in full.items()}
+    ema.update({"online_model." + k: v.clone() for k, v in full.items()})
+    ema.update({"initted": torch.tensor(True), "step": torch.tensor(10)})
+    path = tmp_path / "model-4.pt"
+    torch.save({"step": 123, "model": full, "ema": ema, "scaler": {}}, path)
+    m2, info = harness.load_stage2_checkpoint(str(path))
+    assert info["step"] == 123 and not info["missing"] and not info["unexpected"]
+    assert torch.equal(m2.state_dict()["denoise_fn.linear_out.bias"], full["denoise_fn.linear_out.bias"] + 1.0)
+    assert torch.equal(m2.state_dict()["denoise_fn.time_mlp.3.weight"], full["denoise_fn.time_mlp.3.weight"])
+    m3, _ = harness.load_stage2_checkpoint(str(path), use_ema=False)
+    assert torch.equal(m3.state_dict()["denoise_fn.linear_out.bias"], full["denoise_fn.linear_out.bias"])
+    assert m2.seq_len == 120 and m2.objective == "pred_x0" and m2.num_timesteps == 1000
