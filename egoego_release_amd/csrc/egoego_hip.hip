@@ -58,7 +58,6 @@ struct egoego_ctx {
 };
 
 static const int N_MODEL = 512;
-static int g_stagger = getenv("EGOEGO_STAGGER") ? atoi(getenv("EGOEGO_STAGGER")) : 0;           // perf experiment
 static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debug_trace_buffer
 static int g_chunk = getenv("EGOEGO_CHUNK") ? atoi(getenv("EGOEGO_CHUNK")) : 0;  // windows per denoiser pass (0 = whole batch)
 static int g_fuse_attn = getenv("EGOEGO_FUSE_ATTN") ? atoi(getenv("EGOEGO_FUSE_ATTN")) : 1;  // 0: separate qkv + attention kernels
@@ -278,7 +277,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
-        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
+        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
         EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B};
         if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
     }
@@ -295,7 +294,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         if (g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && !dbg_qkv && nw * H >= 192) {
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)
             ProfScope ps(c, EGOEGO_K_QKV, s);
-            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0, g_ablate, g_stagger, g_trace};
+            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0, g_ablate, g_trace};
             auto kern = qkv_attn_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>, CfgQ<NP>, 4, NP>;
             constexpr int smem = CfgA<NP>::SMEM_BYTES > 2 * 4 * NP * 4096 ? CfgA<NP>::SMEM_BYTES : 2 * 4 * NP * 4096;
             static bool once = false;
@@ -309,7 +308,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             // --- Q, K, V projections (TM:71-73)
             {
                 ProfScope ps(c, EGOEGO_K_QKV, s);
-                GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
+                GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
                 auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
                 static bool once = false;
                 if (!once) {
@@ -331,11 +330,11 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         {
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
             if (small_ln) {
-                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 64, row0 / 64, g_ablate, g_stagger, g_trace};
+                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
                 EpiResLN<NP, 4, 64> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
                 if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
             } else {
-                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
+                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_trace};
                 EpiResLN<NP, 4, 128> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
                 if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
             }
@@ -344,7 +343,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // --- FFN conv 1 + ReLU (TM:111)
         {
             ProfScope ps(c, EGOEGO_K_FFN1, s);
-            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_stagger, g_trace};
+            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
             EpiTiled<true, NP> e{L.b_1, w.F, w.h_plane, N_MODEL / 16};
             if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
         }
@@ -353,11 +352,11 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         {
             ProfScope ps(c, EGOEGO_K_FFN2_LN, s);
             if (small_ln) {
-                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64, g_ablate, g_stagger, g_trace};
+                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
                 EpiResLN<NP, 4, 64> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
                 if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
             } else {
-                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_stagger, g_trace};
+                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace};
                 EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
                 if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
             }
@@ -366,7 +365,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     }
     if (io.run_out) {
         ProfScope ps(c, EGOEGO_K_OUT, s);
-        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c, g_ablate, g_stagger, g_trace};
+        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c, g_ablate, g_trace};
         EpiOut<NP> e{io.out};
         if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
     }

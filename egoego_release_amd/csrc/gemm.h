@@ -30,7 +30,6 @@ struct GemmOperands {
     int ntb;  // token blocks in the grid
     int tblk0;  // first token block of this launch (window-chunked launches)
     int ablate;  // perf-debug only (EGOEGO_ABLATE): 1 = skip global->LDS loads, 2 = skip the epilogue
-    int stagger;  // perf experiment (EGOEGO_STAGGER): second-slot workgroups start this many microseconds late
     unsigned long long* trace;  // perf-debug: [nblocks][4] = {t_start, t_mainloop_end, t_end, hw_id | xcc_id << 32} or nullptr
 };
 
@@ -283,20 +282,9 @@ struct GemmBody {
     }
 };
 
-// Perf experiment: the first 256 blocks of a grid take the first slot of every CU, the next 256 the
-// second; delaying the second group de-phases the two co-resident workgroups so that one's epilogue
-// (HBM writes) overlaps the other's MFMA main loop.
-EG_D void stagger_start(int us) {
-    if (us > 0 && ((blockIdx.x >> 8) & 1)) {
-        const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (long long)us * 100) __builtin_amdgcn_s_sleep(32);  // 100 MHz constant clock
-    }
-}
-
 template <class C, class Epi>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_kernel(GemmOperands g, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    stagger_start(g.stagger);
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int fblk, tblk;
     grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
@@ -307,7 +295,6 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_kernel(GemmOperands g, Ep
 template <class CQK, class EpiQK, class CV, class EpiV>
 __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_kernel(GemmOperands g, EpiQK eqk, EpiV ev, int n_qk_fblocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    stagger_start(g.stagger);
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int fblk, tblk;
     grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
