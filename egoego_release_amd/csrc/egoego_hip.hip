@@ -61,6 +61,7 @@ static const int N_MODEL = 512;
 static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debug_trace_buffer
 static int g_chunk = getenv("EGOEGO_CHUNK") ? atoi(getenv("EGOEGO_CHUNK")) : 0;  // windows per denoiser pass (0 = whole batch)
 static int g_fuse_attn = getenv("EGOEGO_FUSE_ATTN") ? atoi(getenv("EGOEGO_FUSE_ATTN")) : 1;  // 0: separate qkv + attention kernels
+static int g_fuse_tail = getenv("EGOEGO_FUSE_TAIL") ? atoi(getenv("EGOEGO_FUSE_TAIL")) : 1;  // 0: separate fc_ln / ffn1 / ffn2_ln kernels
 static int g_ablate = getenv("EGOEGO_ABLATE") ? atoi(getenv("EGOEGO_ABLATE")) : 0;  // perf-debug only
 
 struct Geometry {
@@ -170,6 +171,24 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperan
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) tr[4] = wall_clock64();
     }
+}
+
+// ------------------------------------------------------------------------------------ fused layer tail
+// One 8-wave workgroup takes 128 tokens through fc+residual+LayerNorm -> FFN-1+ReLU -> FFN-2+residual+LayerNorm.
+// Rows are independent, so the tile a phase reads is exactly the tile the previous phase of the SAME workgroup
+// wrote: it comes back from L2 instead of HBM, and two kernel boundaries per layer disappear.
+template <class C, class ELN, class ETI>
+__global__ __launch_bounds__(C::NT, C::MINW) void layer_tail_kernel(GemmOperands g_fc, ELN e_fc, GemmOperands g_1, ETI e_1,
+                                                                      GemmOperands g_2, ELN e_2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tblk = (int)blockIdx.x + g_fc.tblk0;
+    GemmBody<C, ELN>::run(g_fc, e_fc, 0, tblk, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GemmBody<C, ETI>::run(g_1, e_1, 0, tblk, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GemmBody<C, ELN>::run(g_2, e_2, 0, tblk, smem);
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
@@ -326,6 +345,25 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             }
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_OUT) return 0;
+        if (g_fuse_tail && !small_ln && !last_dbg) {
+            // --- fused layer tail: fc+LN -> FFN-1 -> FFN-2+LN per 128-token block (TM:92-93, 111-114, 135, 139)
+            ProfScope ps(c, EGOEGO_K_FC_LN, s);
+            GemmOperands g1{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+            EpiResLN<NP, 4, 128> e1{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+            GemmOperands g2{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+            EpiTiled<true, NP> e2{L.b_1, w.F, w.h_plane, N_MODEL / 16};
+            GemmOperands g3{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+            EpiResLN<NP, 4, 128> e3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f};
+            auto kern = layer_tail_kernel<CfgB<NP>, EpiResLN<NP, 4, 128>, EpiTiled<true, NP>>;
+            static bool once = false;
+            if (!once) {
+                HIP_TRY(allow_smem(kern, CfgB<NP>::SMEM_BYTES));
+                once = true;
+            }
+            kern<<<dim3(tb_b), dim3(CfgB<NP>::NT), CfgB<NP>::SMEM_BYTES, s>>>(g1, e1, g2, e2, g3, e3);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         // --- fc + residual + LayerNorm (+ padding mask) (TM:92-93, 135)
         {
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
