@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: stage-2 diffusion sampling steps/sec on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -81,8 +81,8 @@ def cpu_baseline(cfg, sd, B, T, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
     ap.add_argument("--window", type=int, default=120)
     ap.add_argument("--precision", type=int, default=3, choices=(1, 3), help="3 = split-bf16 (parity mode), 1 = plain bf16")
