@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libegoego_hip.so")
 SOURCES = ["egoego_hip.hip"]
-HEADERS = ["common.h", "gemm.h", "attention.h", "pointwise.h", os.path.join("..", "..", "include", "egoego_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "egoego_hip.h")]
 
 
 def _hipcc():

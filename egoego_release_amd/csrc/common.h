@@ -25,6 +25,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // one 16-byte chunk (native vector: stays in VGPRs)
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 #define EG_HD __host__ __device__ __forceinline__
 #define EG_D __device__ __forceinline__
@@ -78,6 +80,66 @@ EG_D size_t acc_slot(int m, int f32, int jj, int hf, int K16) {
     return ((((size_t)(m >> 5) * (size_t)K16 + (size_t)((f32 >> 4) + jj)) * 2 + (size_t)hf) << 8) + (size_t)((m & 31) << 3);
 }
 
+// ---- int8-slice operands ("i8x3" mode) ---------------------------------------------------------------
+// A row of an operand is quantised to 16-bit integers q = rint(v / s) with one scale s per row
+// (|q| <= 32639) and stored as two signed int8 slices q = 256*a1 + a2, a2 in [-128, 127].  A product of two rows
+// is then  s_a*s_w * (65536*sum(a1*w1) + 256*sum(a1*w2 + a2*w1))  (+ a dropped 2^-16 term): three int8 MFMAs
+// (v_mfma_i32_32x32x32_i8, twice the bf16 rate, half the operand bytes) into two int32 accumulators.
+// A fragment-tiled int8 plane is [R/32][K/32][2][32][16]: again one 1 KiB block per MFMA operand fragment,
+// lane l reading 16 bytes at block + 16*l.
+struct I8Acc {
+    i32x16 h, m;
+};
+static constexpr float I8_QMAX = 32639.0f;
+
+EG_HD size_t tiled_index_i8(int r, int k, int K32) {
+    return ((((size_t)(r >> 5) * (size_t)K32 + (size_t)(k >> 5)) * 2 + (size_t)((k >> 4) & 1)) << 9) + (size_t)((r & 31) << 4) +
+           (size_t)(k & 15);
+}
+
+// Accumulator order of a 32-feature group for int8 planes: feature 8g + 4hf + c sits at position 16hf + 4g + c,
+// so the 16 accumulator registers of a lane are 16 consecutive bytes (one store per slice per tile).
+EG_HD int acc32(int f) {
+    const int r = f & 31;
+    return (f & ~31) | (((r >> 2) & 1) << 4) | ((r >> 3) << 2) | (r & 3);
+}
+
+// Quantise 16 values with one scale into the two slices (16 bytes each).
+// q = rint(v * inv_scale) comes out of the float adder: u = bits(v * inv_scale + 1.5 * 2^23) = 0x4B400000 + q
+// for |q| < 2^22, so the low byte of u IS the low slice s2 = q - 256 * s1 (as a signed byte) and byte 1 of
+// u + 128 is the high slice s1 = (q + 128) >> 8.  Four values are packed with three byte permutes per slice.
+EG_D void quant16(const float v[16], float inv_scale, u32x4& s1, u32x4& s2) {
+    uint32_t u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[i], inv_scale, 12582912.0f));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t a = u[4 * w], b = u[4 * w + 1], c = u[4 * w + 2], d = u[4 * w + 3];
+        // v_perm_b32(hi, lo, sel): selector bytes 0-3 pick from lo, 4-7 from hi
+        const uint32_t lo01 = __builtin_amdgcn_perm(b, a, 0x0c0c0400u);  // {a.b0, b.b0, 0, 0}
+        const uint32_t lo23 = __builtin_amdgcn_perm(d, c, 0x04000c0cu);  // {0, 0, c.b0, d.b0}
+        s2[w] = lo01 | lo23;
+        const uint32_t a1 = a + 128u, b1 = b + 128u, c1 = c + 128u, d1 = d + 128u;
+        const uint32_t hi01 = __builtin_amdgcn_perm(b1, a1, 0x0c0c0501u);  // {a1.b1, b1.b1, 0, 0}
+        const uint32_t hi23 = __builtin_amdgcn_perm(d1, c1, 0x05010c0cu);  // {0, 0, c1.b1, d1.b1}
+        s1[w] = hi01 | hi23;
+    }
+}
+
+EG_D void dequant16(u32x4 s1, u32x4 s2, float scale, float v[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int a1 = (int)(int8_t)((s1[i >> 2] >> (8 * (i & 3))) & 255);
+        const int a2 = (int)(int8_t)((s2[i >> 2] >> (8 * (i & 3))) & 255);
+        v[i] = (float)(a1 * 256 + a2) * scale;
+    }
+}
+
+// 16-byte slot of lane (m & 31, hf) for feature tile f32 (first feature of the 32-tile) in an int8 plane
+EG_D size_t acc_slot_i8(int m, int f32, int hf, int K32) {
+    return ((((size_t)(m >> 5) * (size_t)K32 + (size_t)(f32 >> 5)) * 2 + (size_t)hf) << 9) + (size_t)((m & 31) << 4);
+}
+
 EG_D void split_bf16(float v, __bf16& hi, __bf16& lo) {
     hi = (__bf16)v;
     lo = (__bf16)(v - (float)hi);
@@ -109,6 +171,17 @@ EG_D void unpack4_hi(uint2 hi, float v[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (float)h[i];
 }
+
+// s_waitcnt through the builtin, not inline asm: hipcc's own wait-count insertion then KNOWS the counter was
+// drained and does not add a second, conservative wait later (after an LDS-DMA every wait it inserts itself
+// is lgkmcnt(0), which would also wait for ds_reads issued a moment ago).  gfx9 encoding:
+// vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8].
+template <int VM, int LGKM>
+EG_D void wait_counts() {
+    static_assert(VM >= 0 && VM <= 63 && LGKM >= 0 && LGKM <= 15, "counter range");
+    __builtin_amdgcn_s_waitcnt((VM & 15) | ((VM >> 4) << 14) | (7 << 4) | (LGKM << 8));
+}
+EG_D void wait_lds() { wait_counts<63, 0>(); }
 
 EG_D int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

@@ -20,6 +20,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef EGOEGO_ABLATE_MAINLOOP
+#define EGOEGO_ABLATE_MAINLOOP 0
+#endif
+
 struct GemmOperands {
     const __bf16* w;  // weights, fragment-tiled [N][K]; lo plane at w + w_plane
     size_t w_plane;
@@ -29,7 +33,7 @@ struct GemmOperands {
     int nfb;  // feature blocks in the grid
     int ntb;  // token blocks in the grid
     int tblk0;  // first token block of this launch (window-chunked launches)
-    int ablate;  // perf-debug only (EGOEGO_ABLATE): 1 = skip global->LDS loads, 2 = skip the epilogue
+    int ablate;  // perf-debug only (EGOEGO_ABLATE): 2 = skip the epilogue, 4 = skip attention
     unsigned long long* trace;  // perf-debug: [nblocks][4] = {t_start, t_mainloop_end, t_end, hw_id | xcc_id << 32} or nullptr
 };
 
@@ -75,10 +79,41 @@ struct GemmCfg {
     static_assert(NSTAGE >= 2 && NSTAGE <= 4 && 2 * NCH < 64, "ring depth / vmcnt range");
 };
 
+// accumulate one (feature tile, token tile) pair for one k-step: bf16 -> fp32 accumulator, int8 -> two int32
+EG_D void acc_zero(f32x16& c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+}
+EG_D void acc_zero(I8Acc& c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c.h[r] = c.m[r] = 0;
+}
+// One of the NP == 2 ? 3 : 1 MFMAs of a product.  The main loop issues part p of ALL of a half's tiles before
+// part p + 1, so two MFMAs on the same accumulator are never back to back.
+template <int NP, bool ACT_ROWS>
+EG_D void mma_part(int part, f32x16& c, bf16x8 wh, bf16x8 wl, bf16x8 ah, bf16x8 al) {
+    if (NP == 1) {
+        c = ACT_ROWS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, c, 0, 0, 0);
+        return;
+    }
+    const bf16x8 w = part == 0 ? wl : wh;
+    const bf16x8 a = part == 1 ? al : ah;
+    c = ACT_ROWS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0);
+}
+template <int NP, bool ACT_ROWS>
+EG_D void mma_part(int part, I8Acc& c, bf16x8 wh, bf16x8 wl, bf16x8 ah, bf16x8 al) {
+    const i32x4 w = __builtin_bit_cast(i32x4, part == 0 ? wl : wh);
+    const i32x4 a = __builtin_bit_cast(i32x4, part == 1 ? al : ah);
+    i32x16& d = part == 2 ? c.h : c.m;
+    d = ACT_ROWS ? __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, d, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a, d, 0, 0, 0);
+}
+
 template <class C, class Epi>
 struct GemmBody {
-    // main loop only: on return acc[ft][tt] holds the pre-epilogue sums of this wave's tile
-    static __device__ void mainloop(const GemmOperands& g, int fblk, int tblk, char* smem, f32x16 (&acc)[C::FT][C::TT]) {
+    // main loop only: on return acc[ft][tt] holds the pre-epilogue sums of this wave's tile.
+    // AccT = f32x16 (bf16 operands) or I8Acc (int8 slices: g.K16 then counts 32-wide k blocks).
+    template <class AccT>
+    static __device__ void mainloop(const GemmOperands& g, int fblk, int tblk, char* smem, AccT (&acc)[C::FT][C::TT]) {
         constexpr int FT = C::FT, TT = C::TT, KS = C::KS, NP = C::NP, WT = C::WT, AT = C::AT, NW = C::NW;
         constexpr int NCH = C::NCH;
         const int wave = wave_id_uniform();
@@ -112,9 +147,7 @@ struct GemmBody {
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int j = 0; j < TT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
 
         const int ns = g.K16 / KS;
         // ---- software pipeline -------------------------------------------------------------------
@@ -131,7 +164,11 @@ struct GemmBody {
         static_assert(FT % 2 == 0, "the pipeline alternates two halves of the wave's feature tiles");
         struct ActFr { bf16x8 h[TT], l[TT]; };
         struct WFr { bf16x8 h[FH], l[FH]; };
+        // perf-debug, compile-time so the shipped loop carries no branches: -DEGOEGO_ABLATE_MAINLOOP=bits
+        // (1 = no global->LDS loads, 8 = no LDS fragment reads, 16 = no waits / barriers)
+        constexpr bool loads_on = !(EGOEGO_ABLATE_MAINLOOP & 1), reads_on = !(EGOEGO_ABLATE_MAINLOOP & 8), sync_on = !(EGOEGO_ABLATE_MAINLOOP & 16);
         auto read_act = [&](int slot, int ks, ActFr& f) {
+            if (!reads_on) return;
             const char* sb = smem + (size_t)slot * C::STAGE_BYTES + lane * 16;
 #pragma unroll
             for (int j = 0; j < TT; ++j) {
@@ -140,6 +177,7 @@ struct GemmBody {
             }
         };
         auto read_w = [&](int slot, int ks, int half, WFr& f) {
+            if (!reads_on) return;
             const char* sb = smem + (size_t)slot * C::STAGE_BYTES + lane * 16;
 #pragma unroll
             for (int i = 0; i < FH; ++i) {
@@ -153,41 +191,32 @@ struct GemmBody {
                 (const __attribute__((address_space(1))) void*)(gp[j] + (size_t)stage * KS * 64),
                 (__attribute__((address_space(3))) void*)(dst + (size_t)j * NW * 1024), 16, 0, 0);
         };
-        // MFMAs of one half (FH x TT accumulator triples).  DMA instruction q of (stage, slot) is issued
-        // after triple q - q0, so the DMA issue cost is paid in the shadow of the matrix pipe.
-        auto mfmas = [&](const ActFr& a, const WFr& w, int half, bool dma, int stage, int slot, int q0) {
-            constexpr int NTRI = FH * TT;
-            constexpr int PER = (NCH + 2 * NTRI - 1) / (2 * NTRI);
+        // MFMAs of one half (FH x TT accumulator triples, part-major).  DMA instruction q of (stage, slot) is issued
+        // after MFMA q - q0, so the DMA issue cost is paid in the shadow of the matrix pipe.
+        auto mfmas = [&](const ActFr& a, const WFr& w, int half, bool dma, int stage, int slot, int q0, auto&& after_first) {
+            constexpr int NPART = NP == 2 ? 3 : 1;
+            constexpr int NMMA = NPART * FH * TT;
+            constexpr int PER = (NCH + 2 * NMMA - 1) / (2 * NMMA);
 #pragma unroll
-            for (int i = 0; i < FH; ++i)
+            for (int part = 0; part < NPART; ++part)
 #pragma unroll
-                for (int j = 0; j < TT; ++j) {
-                    f32x16& c = acc[half * FH + i][j];
-                    if (C::ACT_ROWS) {
-                        if (NP == 2) {
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[j], w.h[i], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[j], w.l[i], c, 0, 0, 0);
-                        }
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[j], w.h[i], c, 0, 0, 0);
-                    } else {
-                        if (NP == 2) {
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l[i], a.h[j], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[i], a.l[j], c, 0, 0, 0);
-                        }
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h[i], a.h[j], c, 0, 0, 0);
+                for (int i = 0; i < FH; ++i)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j) {
+                        mma_part<NP, C::ACT_ROWS>(part, acc[half * FH + i][j], w.h[i], w.l[i], a.h[j], a.l[j]);
+                        const int n = (part * FH + i) * TT + j;
+                        if (n == 0) after_first();
+#pragma unroll
+                        for (int q = 0; q < PER; ++q)
+                            if (q0 + n * PER + q < NCH && dma) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_one(stage, slot, q0 + n * PER + q);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                     }
-                    const int n = i * TT + j;
-#pragma unroll
-                    for (int q = 0; q < PER; ++q)
-                        if (q0 + n * PER + q < NCH && dma) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            issue_one(stage, slot, q0 + n * PER + q);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                }
         };
-        constexpr int DMA_PER_HALF = ((NCH + 2 * FH * TT - 1) / (2 * FH * TT)) * FH * TT;
-        const bool loads_on = !(g.ablate & 1);
+        constexpr int NMMA_HALF = (NP == 2 ? 3 : 1) * FH * TT;
+        constexpr int DMA_PER_HALF = ((NCH + 2 * NMMA_HALF - 1) / (2 * NMMA_HALF)) * NMMA_HALF;
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (d < ns && loads_on) {
@@ -195,12 +224,15 @@ struct GemmBody {
                 for (int j = 0; j < NCH; ++j) issue_one(d, d, j);
             }
         auto wait_stage = [&](int st) {  // stages st+1 .. min(st+D-1, ns-1) may stay in flight
+            if (!sync_on) return;
+            asm volatile("" ::: "memory");
             const int ahead = min(D - 1, ns - 1 - st);
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of the slot about to be refilled are done
+            // vmcnt: my share of stage st landed; lgkmcnt(0): my reads of the slot about to be refilled are done
+            if (ahead >= 2) wait_counts<2 * NCH, 0>();
+            else if (ahead == 1) wait_counts<NCH, 0>();
+            else wait_counts<0, 0>();
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");  // compiler-level fence: no LDS read moves above the barrier
         };
         // ---- software pipeline over k-steps kk = stage*KS + ks ------------------------------------
         // iteration kk:  [new stage: counted vmcnt + barrier]  read act(kk), W-half0(kk)
@@ -209,8 +241,8 @@ struct GemmBody {
         //                MFMA half0(kk)
         // Every batch of ds_reads is followed by 3*FH*TT MFMAs on operands that are ALREADY in registers,
         // so the matrix pipe has work the moment the barrier opens and LDS latency stays in its shadow.
-        ActFr a0, a1;
-        WFr w0, w1;
+        ActFr a0{}, a1{};
+        WFr w0{}, w1{};
         const int nu = ns * KS;
         int slot = 0;   // slot of the stage being read
         int pslot = 0;  // slot of the previous stage (the one being refilled)
@@ -219,11 +251,16 @@ struct GemmBody {
 #pragma unroll
             for (int j = 0; j < NCH; ++j) issue_one(D, D, j);
         }
+        auto nothing = [] {};
         read_act(0, 0, a0);
         read_w(0, 0, 0, w0);
         read_w(0, 0, 1, w1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(a0, w0, 0, false, 0, 0, 0);
+        mfmas(a0, w0, 0, false, 0, 0, 0, nothing);
+        // LDS reads are only ever waited for with NOTHING younger in flight: a batch is issued, a full batch of
+        // MFMAs on operands already in registers runs, and the wait (hipcc puts an lgkmcnt(0) before the first
+        // use, or the explicit one below) then finds the data there.  W-half1 is therefore read right AFTER the
+        // first MFMA of half 0, whose operand wait has just drained the counter.
         auto unit = [&](int kk, ActFr& acur, const ActFr& aprev) {
             const int st = kk / KS, ks = kk - st * KS;
             bool dma = false;
@@ -232,16 +269,20 @@ struct GemmBody {
                 pslot = slot;
                 if (++slot == NS) slot = 0;
                 dma = (st - 1 + NS < ns) && loads_on;
+            } else {
+                wait_lds();  // W-half1 of the previous k-step (issued 11 MFMAs ago): tell hipcc it has landed
             }
             __builtin_amdgcn_sched_barrier(0);
             read_act(slot, ks, acur);
             read_w(slot, ks, 0, w0);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(aprev, w1, 1, dma, st - 1 + NS, pslot, 0);
+            mfmas(aprev, w1, 1, dma, st - 1 + NS, pslot, 0, nothing);
             __builtin_amdgcn_sched_barrier(0);
-            read_w(slot, ks, 1, w1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(acur, w0, 0, dma, st - 1 + NS, pslot, DMA_PER_HALF);
+            mfmas(acur, w0, 0, dma, st - 1 + NS, pslot, DMA_PER_HALF, [&] {
+                __builtin_amdgcn_sched_barrier(0);
+                read_w(slot, ks, 1, w1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
             __builtin_amdgcn_sched_barrier(0);
         };
         int kk = 1;
@@ -251,9 +292,9 @@ struct GemmBody {
         }
         if (kk < nu) {
             unit(kk, a1, a0);
-            mfmas(a1, w1, 1, false, 0, 0, 0);
+            mfmas(a1, w1, 1, false, 0, 0, 0, nothing);
         } else {
-            mfmas(a0, w1, 1, false, 0, 0, 0);
+            mfmas(a0, w1, 1, false, 0, 0, 0, nothing);
         }
         __syncthreads();
         if (g.trace && threadIdx.x == 0) {
@@ -303,6 +344,79 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_kernel(GemmOperands g,
         GemmBody<CQK, EpiQK>::run(g, eqk, fblk, tblk, smem);
     else
         GemmBody<CV, EpiV>::run(g, ev, fblk, tblk, smem);
+}
+
+// ------------------------------------------------------------------------------------ int8-slice blocks
+// "i8x3": both operands are integers q = rint(v / scale) with |q| <= 32639 (one scale per token row, one per
+// weight row), stored as two int8 slices q = 256*s1 + s2.  A product costs three v_mfma_i32_32x32x32_i8
+// (s1*s1 into one int32 accumulator, s1*s2 + s2*s1 into a second; s2*s2 is dropped like lo*lo in split-bf16),
+// each covering K = 32: half the matrix-pipe time of the three bf16 MFMAs.  Two accumulators per tile double
+// the register cost, so a wave's 128f x 64t tile is produced in two sub-passes over 64-feature halves; the
+// weight rows are stored tile-permuted (k_pack_rows_i8) so that each half is a contiguous block.
+struct I8Scales {
+    const float* w;  // [N]  weight row scales, original row order
+    const float* a;  // [Mp] token row scales
+};
+
+// 256 * H + M in one int32: |sum| <= K * (127*127*256 + 2*127*128), which fits for K <= 512 — every contraction
+// here (d_model = 512, d_k = 256, <= 224 keys).  The result is the integer dot product / 256.
+EG_D int i8_combine(int h, int m) { return (h << 8) + m; }
+
+// int32 pair -> fp32, swapped accumulator (lane owns a token)
+EG_D void i8_dequant(const I8Acc& q, f32x16& o, const float* sw8, float sa) {
+    const float sa256 = sa * 256.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w4 = *(const float4*)(sw8 + 8 * g);  // features 8g + 4hf + (0..3); sw8 already includes 4*hf
+        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sa256 * ws[c]);
+    }
+}
+// un-swapped accumulator (lane owns a feature, registers walk tokens)
+EG_D void i8_dequant_rows(const I8Acc& q, f32x16& o, float sw, const float* sa8) {
+    const float sw256 = sw * 256.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 a4 = *(const float4*)(sa8 + 8 * g);
+        const float as[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sw256 * as[c]);
+    }
+}
+
+// One (feature block, token block) of C8::BF*2 features: two sub-passes, each followed by the bf16 path's epilogue
+// on its half.  fblk counts blocks of 2*C8::BF original rows.
+template <class C8, class Epi>
+__device__ __forceinline__ void i8_block(const GemmOperands& g8, const I8Scales& sc, const Epi& epi, int fblk, int tblk, char* smem) {
+    static_assert(C8::FT == 2 && C8::TT == 2 && C8::NP == 2, "sub-pass tile is 64 features x 64 tokens per wave");
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const int wf = wave % C8::NWF, wt = wave / C8::NWF;
+    const int t0 = (tblk * C8::AT + wt * C8::TT) * 32;
+#pragma unroll 1
+    for (int fh = 0; fh < 2; ++fh) {
+        I8Acc q[2][2];
+        GemmBody<C8, Epi>::mainloop(g8, 2 * fblk + fh, tblk, smem, q);
+        const int f0 = ((fblk * C8::NWF + wf) * 4 + fh * 2) * 32;  // original feature index of this half
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (C8::ACT_ROWS)
+                    i8_dequant_rows(q[i][j], acc[i][j], sc.w[f0 + i * 32 + col], sc.a + t0 + j * 32 + 4 * hf);
+                else
+                    i8_dequant(q[i][j], acc[i][j], sc.w + f0 + i * 32 + 4 * hf, sc.a[t0 + j * 32 + col]);
+            }
+        if (g8.ablate & 2) {
+            if (acc[0][0][0] == 123.456f) *(float*)smem = acc[1][1][7];
+            continue;
+        }
+        epi.template run<2, 2>(acc, f0, t0, lane, wf, wt, smem);
+    }
 }
 
 // =================================================================================== epilogues
@@ -452,6 +566,9 @@ struct EpiResLN {
     __bf16* out;
     size_t out_plane;
     float eps;
+    int8_t* q8;       // optional: the same rows as int8 slices (fragment-tiled, accumulator order) for an i8x3 consumer
+    size_t q8_plane;  // bytes between the two slices
+    float* q8_scale;  // [Mp] row scales
     template <int FT, int TT>
     __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem) const {
         static_assert(NWF * FT * 32 == 512, "LayerNorm epilogue needs the whole 512-wide row in the block");
@@ -514,6 +631,7 @@ struct EpiResLN {
             for (int w = 0; w < NWF; ++w) var += red2[slot + w * BT];
             const float rstd = 1.0f / sqrtf(var * (1.0f / 512.0f) + eps);
             const float mk = row_mask ? row_mask[m] : 1.0f;
+            float amax = 0.f;
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -525,13 +643,42 @@ struct EpiResLN {
                     const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
                     float v[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] = ((acc[i][j][8 * jj + c] - mean) * rstd * ga[c] + be[c]) * mk;
-                    u32x4 hi, lo;
-                    split8(v, hi, lo);
-                    const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
-                    *(u32x4*)(out + idx) = hi;
-                    if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
+                    for (int c = 0; c < 8; ++c) {
+                        v[c] = ((acc[i][j][8 * jj + c] - mean) * rstd * ga[c] + be[c]) * mk;
+                        acc[i][j][8 * jj + c] = v[c];
+                        amax = fmaxf(amax, fabsf(v[c]));
+                    }
+                    if (out) {
+                        u32x4 hi, lo;
+                        split8(v, hi, lo);
+                        const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
+                        *(u32x4*)(out + idx) = hi;
+                        if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
+                    }
                 }
+            if (q8) {
+                // row maximum over the 512 features -> one scale per token -> two int8 slices per value
+                float* red3 = red2 + TT * NWF * BT;
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                if (hf == 0) red3[slot + wf * BT] = amax;
+                __syncthreads();
+                float rmax = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red3[slot + w * BT]);
+                const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+                if (wf == 0 && hf == 0) q8_scale[m] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                    u32x4 s1, s2;
+                    quant16(v, inv, s1, s2);
+                    const size_t idx = acc_slot_i8(m, f0 + i * 32, hf, 16);
+                    *(u32x4*)(q8 + idx) = s1;
+                    *(u32x4*)(q8 + q8_plane + idx) = s2;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -41,8 +41,10 @@ enum {
 enum { EGOEGO_PRED_NOISE = 0, EGOEGO_PRED_X0 = 1 };        /* M:235-240 */
 enum { EGOEGO_NOISE_INJECTED = 0, EGOEGO_NOISE_PHILOX = 1, EGOEGO_NOISE_NONE = 2 };
 /* operand precision of every contraction: 3 = split-bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate;
- * meets the 1e-3 parity bar), 1 = plain bf16 operands (fast, does NOT meet it; reported only). */
-enum { EGOEGO_PREC_BF16X3 = 3, EGOEGO_PREC_BF16X1 = 1 };
+ * meets the 1e-3 parity bar), 1 = plain bf16 operands (fast, does NOT meet it; reported only),
+ * 8 = split-bf16 with the d_model-input projections of the fused kernels computed from two int8 slices
+ * per operand (three int8 MFMAs per product, int32 accumulate; same parity bar). */
+enum { EGOEGO_PREC_BF16X3 = 3, EGOEGO_PREC_BF16X1 = 1, EGOEGO_PREC_I8X3 = 8 };
 
 typedef struct egoego_ctx egoego_ctx;
 
@@ -57,7 +59,7 @@ typedef struct {
     int32_t max_timesteps;  /* window + 1; the position table has max_timesteps + 1 rows (TM:180-182) */
     int32_t num_timesteps;  /* diffusion steps S, 1000 */
     int32_t objective;      /* EGOEGO_PRED_X0 | EGOEGO_PRED_NOISE */
-    int32_t precision;      /* EGOEGO_PREC_BF16X3 | EGOEGO_PREC_BF16X1 */
+    int32_t precision;      /* EGOEGO_PREC_BF16X3 | EGOEGO_PREC_BF16X1 | EGOEGO_PREC_I8X3 */
 } egoego_config;
 
 /* fp32 device tensors in the reference checkpoint layout, contiguous. */

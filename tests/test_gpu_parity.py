@@ -1,6 +1,7 @@
 """GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle and the golden vectors the
 reference produced.  Tolerance: the north star's 1e-3 max-abs on pose tensors (written below); the
-split-bf16 path actually lands around 1e-5..1e-4."""
+split-bf16 path actually lands around 1e-5..1e-4, the int8-slice path (i8x3) around 1.5e-4.
+Every oracle / golden comparison runs for both parity-grade operand precisions."""
 import numpy as np
 import pytest
 import torch
@@ -12,6 +13,11 @@ from oracle import egoego_oracle as O
 pytestmark = pytest.mark.gpu
 POSE_TOL = 1e-3      # BASELINE.json north_star: <= 1e-3 max-abs on the final pose tensor
 STAGE_TOL = 3e-4     # per-stage intermediates (values up to ~6)
+
+
+@pytest.fixture(params=[_lib.PREC_BF16X3, _lib.PREC_I8X3], ids=["bf16x3", "i8x3"])
+def prec(request):
+    return request.param
 
 
 def _model(T=120, objective="pred_x0", precision=3):
@@ -30,9 +36,9 @@ def _ref_noise(shape, S, seed=123):
             "steps": torch.stack([torch.randn(shape, generator=g) for _ in range(S)])}
 
 
-def test_stagewise_against_oracle():
+def test_stagewise_against_oracle(prec):
     B, T, H = 2, 120, 4
-    cfg, sd, m = _model(T)
+    cfg, sd, m = _model(T, precision=prec)
     eng = m.hip_engine()
     x_all = torch.randn(B, T, 396, generator=torch.Generator().manual_seed(1120))
     t = torch.tensor([3, 977])
@@ -49,6 +55,7 @@ def test_stagewise_against_oracle():
     for li in (0, 3):
         lt = taps[f"layer{li}"]
         hm = lambda a: a.view(H, B, L, 256).permute(1, 0, 2, 3)
+        # Q/K/V taps: the i8x3 attention kernel keeps them on-chip, so these three stops run the split-bf16 projections
         assert err(eng.debug_stage(xd, xcd, td, li, "q"), hm(lt["q"]) / 16.0) < STAGE_TOL
         assert err(eng.debug_stage(xd, xcd, td, li, "k"), hm(lt["k"])) < STAGE_TOL
         assert err(eng.debug_stage(xd, xcd, td, li, "v"), hm(lt["v"])) < STAGE_TOL
@@ -57,8 +64,8 @@ def test_stagewise_against_oracle():
 
 
 @pytest.mark.parametrize("T,tags", [(120, ("t0", "t500", "t999", "tmix")), (30, ("t0", "tmix")), (196, ("t0", "tmix"))])
-def test_denoise_against_reference_golden(golden, T, tags):
-    cfg, sd, m = _model(T)
+def test_denoise_against_reference_golden(golden, T, tags, prec):
+    cfg, sd, m = _model(T, precision=prec)
     x_all = torch.randn(2, T, 396, generator=torch.Generator().manual_seed(int(golden[f"denoise_T{T}_seed"])))
     x, xc = x_all[..., :198].contiguous().cuda(), x_all[..., 198:].contiguous().cuda()
     tt = {"t0": [0, 0], "t500": [500, 500], "t999": [999, 999], "tmix": [3, 977]}
@@ -67,8 +74,8 @@ def test_denoise_against_reference_golden(golden, T, tags):
         assert np.abs(y - golden[f"denoise_T{T}_{tag}"]).max() < POSE_TOL, tag
 
 
-def test_denoise_padding_mask_golden(golden):
-    cfg, sd, m = _model()
+def test_denoise_padding_mask_golden(golden, prec):
+    cfg, sd, m = _model(precision=prec)
     x_all = torch.randn(2, 120, 396, generator=torch.Generator().manual_seed(77))
     pm = torch.ones(2, 1, 121).bool()
     pm[0, 0, 100:] = False
@@ -79,8 +86,8 @@ def test_denoise_padding_mask_golden(golden):
 
 
 @pytest.mark.parametrize("objective", ["pred_x0", "pred_noise"])
-def test_p_sample_golden(golden, objective):
-    cfg, sd, m = _model(objective=objective)
+def test_p_sample_golden(golden, objective, prec):
+    cfg, sd, m = _model(objective=objective, precision=prec)
     g = torch.Generator().manual_seed(2024)
     x = torch.randn(2, 120, 198, generator=g)
     xc = torch.randn(2, 120, 198, generator=g)
@@ -110,10 +117,10 @@ def test_p_sample_default_noise_uses_torch_generator():
 
 
 @pytest.mark.parametrize("tag,B,S", [("b1_s10", 1, 10), ("b2_s50", 2, 50), ("b1_s1000", 1, 1000)])
-def test_sample_chain_against_reference_golden(golden, tag, B, S):
+def test_sample_chain_against_reference_golden(golden, tag, B, S, prec):
     """Full sample() with the reference's own noise draws: BASELINE config 1 (B=1, 10 steps), a
     50-step B=2 chain, and the full 1000-step chain."""
-    cfg, sd, m = _model()
+    cfg, sd, m = _model(precision=prec)
     m.num_timesteps = S  # the same truncation the reference fixture used
     xs, cm = make_head_windows(B, 120, seed=11)
     y = m.sample(xs.cuda(), cm.cuda(), noise=_ref_noise(xs.shape, S)).cpu().numpy()
@@ -123,9 +130,9 @@ def test_sample_chain_against_reference_golden(golden, tag, B, S):
     assert np.abs(y).max() <= 1.0
 
 
-def test_trajectory_stays_close_over_many_steps():
+def test_trajectory_stays_close_over_many_steps(prec):
     """Early divergence check: per-step max error against the oracle over a 25-step window of the chain."""
-    cfg, sd, m = _model()
+    cfg, sd, m = _model(precision=prec)
     eng = m.hip_engine()
     sched = O.make_schedule(1000)
     B, T = 2, 120
@@ -142,10 +149,10 @@ def test_trajectory_stays_close_over_many_steps():
     assert worst < POSE_TOL, worst
 
 
-def test_full_size_properties_b256():
+def test_full_size_properties_b256(prec):
     """BASELINE config 3 size (B=256, T=120): determinism, shard invariance of the Philox noise,
     prefix in-painting, finiteness and the final clamp — properties that need no CPU oracle run."""
-    cfg, sd, m = _model()
+    cfg, sd, m = _model(precision=prec)
     eng = m.hip_engine()
     B, T = 256, 120
     xs, cm = make_head_windows(B, T, seed=21)
@@ -214,10 +221,10 @@ def test_error_paths():
         m.hip_engine()
 
 
-def test_ddim_against_oracle_restatement():
+def test_ddim_against_oracle_restatement(prec):
     """BASELINE config 4's sampler.  No reference oracle exists for DDIM (the reference only has the ancestral
     chain): the check is against oracle.ddim_loop, a restatement of the published eta=0 update."""
-    cfg, sd, m = _model()
+    cfg, sd, m = _model(precision=prec)
     sched = O.make_schedule(1000)
     B, T = 2, 120
     xs, cm = make_head_windows(B, T, seed=8)
@@ -235,13 +242,14 @@ def test_ddim_against_oracle_restatement():
 
 @pytest.mark.parametrize("B,T,n_head,n_layers", [(1, 1, 4, 4), (3, 2, 4, 4), (5, 31, 4, 4), (3, 63, 4, 4), (2, 127, 4, 4),
                                                   (2, 128, 4, 4), (1, 223, 4, 4), (2, 50, 2, 1), (2, 120, 8, 2)])
-def test_shape_edge_cases_against_oracle(B, T, n_head, n_layers):
+def test_shape_edge_cases_against_oracle(B, T, n_head, n_layers, prec):
     """Minimum window (T=1), every key-tile boundary (L = 32/64/128/129), the maximum supported window
     (T=223), odd batches, and other head / layer counts than the shipped checkpoint's."""
     cfg = ModelConfig(max_timesteps=T + 1, n_head=n_head, n_dec_layers=n_layers)
     sd = make_weights(cfg, 3)
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
     m.load_state_dict(sd, strict=False)
+    m.hip_precision = prec  # i8x3 covers 96 < L <= 128 (one workgroup per window and head); other lengths run split-bf16
     m = m.cuda()
     g = torch.Generator().manual_seed(100 * T + B)
     x_all = torch.randn(B, T, 396, generator=g)
@@ -268,11 +276,11 @@ def test_unsupported_shapes_fail_loudly():
         m.denoise(x, torch.zeros(1, dtype=torch.long, device="cuda"), x)
 
 
-def test_batch_size_invariance_covers_large_batch_kernels():
+def test_batch_size_invariance_covers_large_batch_kernels(prec):
     """Windows are independent, and every kernel accumulates a given output element in the same order whatever
     its tiling: the first windows of a B=256 run (fused QKV+attention, fused layer tail, 128-token LayerNorm
     tiles) must equal a B=3 run (unfused kernels, 64-token tiles) — and the B=3 run is checked against the oracle."""
-    cfg, sd, m = _model()
+    cfg, sd, m = _model(precision=prec)
     eng = m.hip_engine()
     g = torch.Generator().manual_seed(77)
     B = 256
