@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
         }
         float p[4][16];
         float mx = -INFINITY;
-        const float sq256 = sq * 256.0f;
+        // logits in units of log2(e): softmax through v_exp_f32 (2^x), one instruction per probability
+        const float sq256 = sq * 256.0f * 1.44269504088896f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[kt][r] = expf(p[kt][r] - mx);
+                p[kt][r] = __builtin_amdgcn_exp2f(p[kt][r] - mx);
                 sum += p[kt][r];
             }
         sum += __shfl_xor(sum, 32);
