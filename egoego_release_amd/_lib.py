@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libegoego_hip.so")
+LIB_PATH = os.environ.get("EGOEGO_HIP_LIB") or os.path.join(_PKG, "libegoego_hip.so")  # override: perf-debug builds only
 
 ABI_VERSION = 1
 PRED_NOISE, PRED_X0 = 0, 1

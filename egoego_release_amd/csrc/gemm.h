@@ -575,14 +575,17 @@ struct EpiResLN {
         const int hf = lane >> 5, col = lane & 31;
         float* red1 = (float*)smem;     // [TT][NWF][BT]  per-wave partial sums
         float* red2 = red1 + TT * NWF * BT;
-        // A token is one lane (col) of one token tile j, so LayerNorm is independent per j: the tiles are
-        // processed one after the other (fenced) to keep the live register set small — doing both at once
-        // spills.
+        // A token is one lane (col) of one token tile j.  The three reductions over the 512 features (sum, centred
+        // squares, |max| for the int8 side output) are each done for ALL token tiles at once: one LDS exchange and
+        // one barrier per reduction, whatever TT is.
+        float* red3 = red2 + TT * NWF * BT;
+        int slot[TT];
+        float mean[TT], rstd[TT], amax[TT];
+        // ---- y = acc + bias + residual, row sums
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
-            const int slot = (j * NWF) * BT + (wt * TT + j) * 32 + col;
-            // y = acc + bias + residual
+            slot[j] = (j * NWF) * BT + (wt * TT + j) * 32 + col;
             float s1 = 0.f;
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -608,30 +611,38 @@ struct EpiResLN {
                     }
                 }
             s1 += __shfl_xor(s1, 32);
-            if (hf == 0) red1[slot + wf * BT] = s1;
-            __syncthreads();
-            float mean = 0.f;
+            if (hf == 0) red1[slot[j] + wf * BT] = s1;
+        }
+        __syncthreads();
+        // ---- biased variance of the centred values (two-pass, like the reference's LayerNorm)
 #pragma unroll
-            for (int w = 0; w < NWF; ++w) mean += red1[slot + w * BT];
-            mean *= (1.0f / 512.0f);
-            // biased variance of the centred values (two-pass, like the reference's LayerNorm)
+        for (int j = 0; j < TT; ++j) {
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWF; ++w) sm += red1[slot[j] + w * BT];
+            mean[j] = sm * (1.0f / 512.0f);
             float s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float d = acc[i][j][r] - mean;
+                    const float d = acc[i][j][r] - mean[j];
                     s2 += d * d;
                 }
             s2 += __shfl_xor(s2, 32);
-            if (hf == 0) red2[slot + wf * BT] = s2;
-            __syncthreads();
+            if (hf == 0) red2[slot[j] + wf * BT] = s2;
+        }
+        __syncthreads();
+        // ---- normalise, scale/shift, padding mask, store
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int m = t0 + j * 32 + col;
             float var = 0.f;
 #pragma unroll
-            for (int w = 0; w < NWF; ++w) var += red2[slot + w * BT];
-            const float rstd = 1.0f / sqrtf(var * (1.0f / 512.0f) + eps);
+            for (int w = 0; w < NWF; ++w) var += red2[slot[j] + w * BT];
+            rstd[j] = 1.0f / sqrtf(var * (1.0f / 512.0f) + eps);
             const float mk = row_mask ? row_mask[m] : 1.0f;
-            float amax = 0.f;
+            amax[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -644,9 +655,9 @@ struct EpiResLN {
                     float v[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        v[c] = ((acc[i][j][8 * jj + c] - mean) * rstd * ga[c] + be[c]) * mk;
+                        v[c] = ((acc[i][j][8 * jj + c] - mean[j]) * rstd[j] * ga[c] + be[c]) * mk;
                         acc[i][j][8 * jj + c] = v[c];
-                        amax = fmaxf(amax, fabsf(v[c]));
+                        amax[j] = fmaxf(amax[j], fabsf(v[c]));
                     }
                     if (out) {
                         u32x4 hi, lo;
@@ -657,14 +668,19 @@ struct EpiResLN {
                     }
                 }
             if (q8) {
-                // row maximum over the 512 features -> one scale per token -> two int8 slices per value
-                float* red3 = red2 + TT * NWF * BT;
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
-                if (hf == 0) red3[slot + wf * BT] = amax;
-                __syncthreads();
+                amax[j] = fmaxf(amax[j], __shfl_xor(amax[j], 32));
+                if (hf == 0) red3[slot[j] + wf * BT] = amax[j];
+            }
+        }
+        if (q8) {
+            // row maximum over the 512 features -> one scale per token -> two int8 slices per value
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                const int m = t0 + j * 32 + col;
                 float rmax = 0.f;
 #pragma unroll
-                for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red3[slot + w * BT]);
+                for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red3[slot[j] + w * BT]);
                 const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
                 if (wf == 0 && hf == 0) q8_scale[m] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
 #pragma unroll
@@ -679,7 +695,6 @@ struct EpiResLN {
                     *(u32x4*)(q8 + q8_plane + idx) = s2;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 };
