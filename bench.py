@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_I8_TOPS = 5000.0      # dense int8 MFMA: twice the bf16 rate (same guide; its micro-benchmark ceiling is >= 3944)
 
 
 def flops_per_window_step(T, d_feats=198, d_model=512, n_head=4, d_k=256, n_layers=4):
@@ -33,9 +34,15 @@ def flops_per_window_step(T, d_feats=198, d_model=512, n_head=4, d_k=256, n_laye
 
 
 def qkv_attn_flops_per_launch(B, T, d_model=512, n_head=4, d_k=256):
-    """Algorithmic FLOPs of one launch of the fused kernel: Q/K/V projections + QK^T + PV (one layer)."""
+    """Algorithmic FLOPs of one launch of the attention-layer kernel: Q/K/V projections + QK^T + PV (one layer)."""
     L, HD = T + 1, n_head * d_k
     return B * (2 * L * d_model * 3 * HD + 4 * L * L * HD)
+
+
+def tail_flops_per_launch(B, T, d_model=512, n_head=4, d_k=256):
+    """Algorithmic FLOPs of one launch of the layer-tail kernel: fc + FFN-1 + FFN-2 (one layer)."""
+    L, HD = T + 1, n_head * d_k
+    return B * L * (2 * HD * d_model + 4 * d_model * d_model)
 
 
 def cpu_baseline(cfg, sd, B, T, budget_s=25.0):
@@ -85,9 +92,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
     ap.add_argument("--window", type=int, default=120)
-    ap.add_argument("--precision", type=int, default=3, choices=(1, 3), help="3 = split-bf16 (parity mode), 1 = plain bf16")
+    ap.add_argument("--precision", type=int, default=8, choices=(1, 3, 8),
+                    help="8 = i8x3 attention kernel + split-bf16 elsewhere (parity-grade, default), 3 = split-bf16 everywhere "
+                         "(parity-grade), 1 = plain bf16 (NOT parity-grade)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-kernel", default="qkv")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,7 +155,7 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.profile_begin(args.profile_kernel)
+    eng.profile_begin("qkv")  # HIP events around every launch of the attention-layer kernel inside the timed region
     t0 = time.perf_counter()
     run_steps(K, S - 1 - W)
     if dist:
@@ -164,17 +172,50 @@ def main():
         el = tmax.item()
     finite = bool(torch.isfinite(x).all().item())
 
-    traffic = None
-    try:  # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (profiles/)
+    # the other heavy kernel (layer tail), timed the same way over a few extra untimed steps
+    eng.profile_begin("fc_ln")
+    run_steps(min(K, 10), S - 1 - W - K)
+    torch.cuda.synchronize()
+    t_us, t_n = eng.profile_end()
+
+    traffic = {}
+    try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (profiles/)
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            traffic = json.load(f)["kernels"]["qkv_attn_kernel:EpiQK"]["hbm_bytes_per_launch"] if (B, T, args.precision) == (256, 120, 3) else None
+            tj = json.load(f)
+        if (B, T, args.precision) == (tj.get("batch"), tj.get("window"), tj.get("precision")):
+            traffic = tj["kernels"]
     except Exception:
-        traffic = None
+        traffic = {}
 
     if rank == 0:
         steps_per_s = world * K / el
         fl_step = flops_per_window_step(T) * B
-        qkv_ach = qkv_attn_flops_per_launch(B, T) / (k_us * 1e-6) / 1e12 if k_n else None
+        i8 = args.precision == 8 and 96 < T + 1 <= 128
+        attn_name = "attn_layer_i8_kernel" if i8 else "qkv_attn_kernel"
+        attn_peak = PEAK_I8_TOPS if i8 else PEAK_BF16_TFLOPS
+        attn_ach = qkv_attn_flops_per_launch(B, T) / (k_us * 1e-6) / 1e12 if k_n else None
+        tail_ach = tail_flops_per_launch(B, T) / (t_us * 1e-6) / 1e12 if t_n else None
+        L = T + 1
+        attn_roof = {
+            "bound": "mfma", "kernel": attn_name + (" (Q/K/V projections, softmax and PV of one window x head per workgroup, int8 slices; "
+                                                    "K, V and the probabilities stay in LDS/registers)" if i8 else
+                                                    " (fused Q/K/V projection + attention, split-bf16)"),
+            "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if i8 else "TFLOP/s",
+            "frac": (attn_ach / attn_peak) if attn_ach else None,
+            "traffic": (traffic.get(attn_name) or {}).get("hbm_bytes_per_launch"),
+            "algorithmic_bytes": (2 * B * L * 512 + 4 * B * L * 1024 + 3 * 2 * 512 * 1024) if i8 else (4 * B * L * (512 + 1024) + 6.3e6),
+            "launch_us": k_us, "launches": k_n, "share_of_step": 4 * k_us / (1e3 * el / K) / 1e3 if k_n else None,
+            "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time measured inside the timed region; three "
+                    "MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe utilisation is 3x this fraction. "
+                    "The main loops are bound by L2->LDS operand bandwidth, not by the pipe (DESIGN.md, tools/microbench/dma_bw.hip)."}
+        tail_roof = {
+            "bound": "mfma", "kernel": "layer_tail_kernel (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 128 tokens, split-bf16)",
+            "achieved": tail_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (tail_ach / PEAK_BF16_TFLOPS) if tail_ach else None,
+            "traffic": (traffic.get("layer_tail_kernel") or {}).get("hbm_bytes_per_launch"),
+            "algorithmic_bytes": 4 * B * L * (1024 + 512 + 512) + 4.2e6,
+            "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * el / K) / 1e3 if t_n else None,
+            "note": "timed over extra steps right after the timed region; split-bf16 issues 3 MFMAs per product (pipe utilisation 3x)"}
+        dominant, other = (attn_roof, tail_roof) if (k_us or 0) >= (t_us or 0) else (tail_roof, attn_roof)
         out = {
             "metric": "diffusion-steps/sec (B=256, T=120, 22-joint)",
             "value": steps_per_s,
@@ -186,7 +227,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)" if args.precision == 3 else "bf16",
+            "dtype": {8: "i8x3 + bf16x3 (attention layer: 2 x int8 slices per operand, int32 accumulate; rest: split-bf16, fp32 accumulate)",
+                      3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)", 1: "bf16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: B={B} windows/GPU x T={T} frames x 198 feats, 1000-step DDPM chain "
                                    f"(steps {S - 1 - W}..{S - W - K} timed), in-kernel Philox noise, synthetic seeded weights",
@@ -196,14 +238,8 @@ def main():
             "step_tflops_algorithmic": fl_step * steps_per_s / world / 1e12,
             "step_frac_of_bf16_peak": fl_step * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS,
             "output_finite": finite,
-            "roofline": {"bound": "mfma", "kernel": "qkv_attn_kernel (fused Q/K/V projection + attention of one window x head per workgroup; 62% of step FLOPs)",
-                         "achieved": qkv_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (qkv_ach / PEAK_BF16_TFLOPS) if qkv_ach else None, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 PMC pass, FETCH_SIZE x2 + WRITE_SIZE); "
-                                         "algorithmic bytes per launch (h in, O out, weights) = 4*B*L*(512 + 1024) + 6 MB = 197 MB; K and V still round-trip through L2/HBM inside the kernel",
-                         "launch_us": k_us, "launches": k_n,
-                         "note": "algorithmic FLOPs (1x) over measured launch time; split-bf16 issues 3 MFMAs per product, "
-                                 "so MFMA-pipe utilisation is 3x this fraction"},
+            "roofline": dominant,
+            "roofline_second_kernel": other,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

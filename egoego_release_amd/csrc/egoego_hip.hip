@@ -346,12 +346,13 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         const bool q8_out = i8 && attn_geom && li + 1 < c->cfg.n_dec_layers;
         int8_t* const q8p = q8_out ? w.hA8 : nullptr;
         if (fused_attn && i8) {
-            ProfScope ps(c, EGOEGO_K_QKV, s);
             if (li == 0) {  // later layers get their int8 rows from the previous layer's LayerNorm epilogue
+                ProfScope ps(c, EGOEGO_K_EMBED, s);
                 k_quant_rows<<<rows / 32, 256, 0, s>>>(w.hA + (size_t)row0 * N_MODEL, w.h_plane, w.hA8 + (size_t)row0 * N_MODEL, w.h_plane,
                                                        w.hA_scale + row0);
                 HIP_TRY(hipGetLastError());
             }
+            ProfScope ps(c, EGOEGO_K_QKV, s);
             if (g_i8 != 2) {
                 AttnLayerArgs al{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, L.b_qkv, w.hA8, w.h_plane, w.hA_scale, w.O, w.o_plane, HD / 16,
                                  1.0f / sqrtf((float)c->cfg.d_k), H, g.L, w0 * H, g_ablate, g_trace};
@@ -418,9 +419,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
             GemmOperands g1{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_trace};
             EpiResLN<NP, 4, 128> e1{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
-            GemmOperands g2{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+            // perf-debug: the three phases stamp disjoint parts of the trace buffer
+            GemmOperands g2{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace ? g_trace + 2048 : nullptr};
             EpiTiled<true, NP> e2{L.b_1, w.F, w.h_plane, N_MODEL / 16};
-            GemmOperands g3{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+            GemmOperands g3{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace ? g_trace + 4096 : nullptr};
             EpiResLN<NP, 4, 128> e3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
             auto kern = layer_tail_kernel<CfgB<NP>, EpiResLN<NP, 4, 128>, EpiTiled<true, NP>>;
             static bool once = false;

@@ -2,6 +2,7 @@
 //   mode 0: global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave-instruction)
 //   mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128
 //   mode 2: global_load_dwordx4 -> VGPR only (no LDS write)
+//   mode 3: LDS-DMA with a workgroup barrier per iteration (the GEMM ring's synchronisation, no MFMAs)
 // One workgroup per CU (LDS-limited), NW waves; every wave streams `iters` x PIECES KiB from a buffer of
 // `span` bytes that all workgroups share (L2-resident when small) or that is private per workgroup (HBM).
 #include <hip/hip_runtime.h>
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(512) void k(const char* src, size_t span, size_t wg
 #pragma unroll
         for (int p = 0; p < PIECES; ++p) {
             const char* g = base + (off + (size_t)p * 1024) % span + lane * 16;
-            if (MODE == 0) {
+            if (MODE == 0 || MODE == 3) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
             } else {
@@ -34,6 +35,9 @@ __global__ __launch_bounds__(512) void k(const char* src, size_t span, size_t wg
         }
         if (MODE == 0) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // previous iteration's pieces landed
+        } else if (MODE == 3) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            __builtin_amdgcn_s_barrier();
         } else if (MODE == 1) {
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) *(u32x4*)(dst + p * 1024 + lane * 16) = r[p];
@@ -79,6 +83,10 @@ int main() {
         run<0, 6>("lds-dma", nw, 8 << 20, true, buf, sink);
         run<2, 6>("vgpr only", nw, 8 << 20, true, buf, sink);
     }
+    run<3, 5>("lds-dma + barrier", 8, 1 << 20, false, buf, sink);
+    run<3, 5>("lds-dma + barrier", 8, 4 << 20, false, buf, sink);
+    run<0, 5>("lds-dma", 8, 4 << 20, false, buf, sink);
+    run<3, 6>("lds-dma + barrier", 4, 1 << 20, false, buf, sink);
     run<0, 2>("lds-dma", 4, 1 << 20, false, buf, sink);
     run<0, 12>("lds-dma", 4, 1 << 20, false, buf, sink);
     run<2, 12>("vgpr only", 4, 1 << 20, false, buf, sink);

@@ -23,6 +23,8 @@ def main(paths):
     counters = sorted({c for k in acc.values() for c in k})
     print("kernel," + ",".join(counters) + ",launches")
     for k, d in sorted(acc.items()):
+        if k.startswith("void at::") or k.startswith("__amd"):  # torch / runtime helpers of bench.py's setup
+            continue
         n = max(len(v) for v in d.values())
         print(k + "," + ",".join(f"{sum(d[c]) / len(d[c]):.4g}" if c in d else "" for c in counters) + f",{n}")
 

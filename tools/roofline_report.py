@@ -7,10 +7,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B, T, L, HD, DM, D = 256, 120, 121, 1024, 512, 198
-PEAK_TF, PEAK_HBM = 2500.0, 8.0  # TFLOP/s bf16 dense, TB/s (MI355X_MICROARCH.md)
+PEAK_TF, PEAK_I8, PEAK_HBM = 2500.0, 5000.0, 8.0  # TFLOP/s bf16 dense, TOP/s int8 dense, TB/s (MI355X_MICROARCH.md)
 
 ALG = {  # kernel tag -> (what, algorithmic FLOPs per launch, algorithmic HBM bytes per launch)
-    "qkv_attn_kernel": ("Q/K/V projections + attention (one layer)", B * (2 * L * DM * 3 * HD + 4 * L * L * HD), 4 * B * L * (DM + HD) + 6.3e6),
+    "attn_layer_i8_kernel": ("Q/K/V projections + softmax + PV (one layer), int8 slices", B * (2 * L * DM * 3 * HD + 4 * L * L * HD),
+                             2 * B * L * DM + 4 * B * L * HD + 3.2e6),
     "layer_tail_kernel": ("fc+LN, FFN-1, FFN-2+LN (one layer)", B * L * (2 * HD * DM + 4 * DM * DM), 4 * B * L * (HD + DM + DM) + 4.2e6),
     "EpiEmbed": ("embed GEMM + time token + pos-emb", 2 * B * T * 2 * D * DM, 4 * B * T * 2 * D + 4 * B * L * DM),
     "EpiOut": ("linear_out + DDPM posterior", 2 * B * T * DM * D, 4 * B * L * DM + 3 * 4 * B * T * D),
@@ -26,12 +27,13 @@ def main():
         us = float(st["AverageNs"]) / 1e3
         tr = next((v for k, v in traffic.items() if tag in k), None)
         hbm = tr["hbm_bytes_per_launch"] if tr else None
-        rows.append((tag, what, us, float(st["Percentage"]), flops / us / 1e6, flops / us / 1e6 / PEAK_TF, 3 * flops / us / 1e6 / PEAK_TF,
+        peak = PEAK_I8 if "i8" in tag else PEAK_TF
+        rows.append((tag, what, us, float(st["Percentage"]), flops / us / 1e6, flops / us / 1e6 / peak, 3 * flops / us / 1e6 / peak,
                      abytes / 1e6, (hbm or 0) / 1e6, (hbm or 0) / us / 1e6))
-    out = ["# Per-kernel roofline, round 1 (B=256, T=120, split-bf16; from the files in this directory)", "",
-           "MFMA bound: 2.5 PFLOP/s dense bf16; split-bf16 issues 3 MFMAs per algorithmic product, so the algorithmic fraction is capped at 33 %.",
+    out = ["# Per-kernel roofline, round 1 (B=256, T=120, precision i8x3: int8-slice attention layer + split-bf16 elsewhere; from the files in this directory)", "",
+           "MFMA bound: 2.5 PFLOP/s dense bf16, 5 POP/s dense int8; both split-bf16 and the int8 slices issue 3 MFMAs per algorithmic product, so the algorithmic fraction is capped at 33 %.",
            "HBM bound: 8 TB/s.  `traffic` = (2·FETCH_SIZE + WRITE_SIZE)·1024 from the PMC passes.", "",
-           "| kernel | what | avg µs | % of GPU time | algorithmic TFLOP/s | frac of bf16 peak | MFMA-pipe frac (×3) | algorithmic MB | measured HBM MB | HBM TB/s |",
+           "| kernel | what | avg µs | % of GPU time | algorithmic TFLOP/s (TOP/s) | frac of the dtype's peak | MFMA-pipe frac (×3) | algorithmic MB | measured HBM MB | HBM TB/s |",
            "|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
         out.append(f"| `{r[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.1f} | {r[4]:.0f} | {r[5]:.3f} | {r[6]:.3f} | {r[7]:.0f} | {r[8]:.0f} | {r[9]:.2f} |")
