@@ -857,6 +857,24 @@ int egoego_rot6d_to_matrix(const float* d_in, float* d_out, int64_t n, void* str
     return 0;
 }
 
+int egoego_convert_model_res(const float* d_x, const float* d_rec_quat, const float* d_jpos_min, const float* d_jpos_max,
+                             const int32_t* parents_host, int head_idx, int B, int T, float* d_aa, float* d_root, float* d_head,
+                             void* stream) {
+    if (!d_x || !d_rec_quat || !d_jpos_min || !d_jpos_max || !parents_host || !d_aa || !d_root || !d_head)
+        return fail(EGOEGO_E_INVALID, "null argument");
+    if (B < 1 || T < 1 || head_idx < 0 || head_idx >= 22) return fail(EGOEGO_E_INVALID, "bad shape (B=%d, T=%d, head_idx=%d)", B, T, head_idx);
+    ConvertArgs a{d_x, d_rec_quat, d_jpos_min, d_jpos_max, d_aa, d_root, d_head, {}, head_idx, B, T};
+    for (int j = 0; j < 22; ++j) {
+        a.parents[j] = parents_host[j];
+        if (j > 0 && (a.parents[j] < 0 || a.parents[j] >= j)) return fail(EGOEGO_E_INVALID, "parents[%d] = %d is not an earlier joint", j, a.parents[j]);
+    }
+    const int64_t n = (int64_t)B * T * 22;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    k_convert_model_res<<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 /* perf-debug only (not in the public header): per-block timestamps of every GEMM launch go to `buf`
  * ([grid][4] u64, overwritten by each launch); nullptr disables. */
 int egoego_debug_trace_buffer(unsigned long long* buf) {

@@ -201,6 +201,115 @@ __global__ void k_rot6d_to_matrix(const float* __restrict__ in, float* __restric
     }
 }
 
+// ---------------------------------------------------------------- post-loop conversion chain
+// convert_model_res_to_data (M:469-525) + quat_ik (amass_diffusion_dataset.py:109-125) for one batch of windows, one
+// thread per (window, frame, joint).  Every step follows the torch chain of harness.py / rotations.py (themselves
+// restatements of the pytorch3d definitions the reference calls) so that the two agree to rounding:
+//   6D -> matrix -> quaternion (M:493-494); un-canonicalise: q = standardize(rec * q) (M:496);
+//   -> matrix (M:505); IK: local = standardize(inv(q_parent) * q_child) via the matrix -> quaternion round trip of
+//   quat_ik; -> matrix -> quaternion -> axis-angle (M:507);  root / head positions de-normalised and rotated by rec (M:498-501).
+struct Quat {
+    float w, x, y, z;
+};
+EG_D Quat q_std(Quat q) { return q.w < 0.f ? Quat{-q.w, -q.x, -q.y, -q.z} : q; }
+EG_D Quat q_mul(Quat a, Quat b) {
+    return Quat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+EG_D void rot6d_rows(const float* in6, float (&m)[9]) {
+    const float a1x = in6[0], a1y = in6[1], a1z = in6[2], a2x = in6[3], a2y = in6[4], a2z = in6[5];
+    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float dt = b1x * a2x + b1y * a2y + b1z * a2z;
+    const float cx = a2x - dt * b1x, cy = a2y - dt * b1y, cz = a2z - dt * b1z;
+    const float n2 = fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-12f);
+    const float b2x = cx / n2, b2y = cy / n2, b2z = cz / n2;
+    m[0] = b1x; m[1] = b1y; m[2] = b1z;
+    m[3] = b2x; m[4] = b2y; m[5] = b2z;
+    m[6] = b1y * b2z - b1z * b2y;
+    m[7] = b1z * b2x - b1x * b2z;
+    m[8] = b1x * b2y - b1y * b2x;
+}
+// largest-of-(w, x, y, z) branch, denominators clamped at 0.1, result with w >= 0 (rotations.matrix_to_quaternion)
+EG_D Quat mat_to_quat(const float (&m)[9]) {
+    const float qa[4] = {sqrtf(fmaxf(1.0f + m[0] + m[4] + m[8], 0.f)), sqrtf(fmaxf(1.0f + m[0] - m[4] - m[8], 0.f)),
+                         sqrtf(fmaxf(1.0f - m[0] + m[4] - m[8], 0.f)), sqrtf(fmaxf(1.0f - m[0] - m[4] + m[8], 0.f))};
+    int best = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (qa[i] > qa[best]) best = i;
+    const float d = 2.0f * fmaxf(qa[best], 0.1f);
+    Quat q;
+    if (best == 0) q = Quat{qa[0] * qa[0], m[7] - m[5], m[2] - m[6], m[3] - m[1]};
+    else if (best == 1) q = Quat{m[7] - m[5], qa[1] * qa[1], m[3] + m[1], m[2] + m[6]};
+    else if (best == 2) q = Quat{m[2] - m[6], m[3] + m[1], qa[2] * qa[2], m[5] + m[7]};
+    else q = Quat{m[3] - m[1], m[6] + m[2], m[7] + m[5], qa[3] * qa[3]};
+    return q_std(Quat{q.w / d, q.x / d, q.y / d, q.z / d});
+}
+EG_D void quat_to_mat(Quat q, float (&m)[9]) {
+    const float two_s = 2.0f / (q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    m[0] = 1 - two_s * (q.y * q.y + q.z * q.z); m[1] = two_s * (q.x * q.y - q.z * q.w); m[2] = two_s * (q.x * q.z + q.y * q.w);
+    m[3] = two_s * (q.x * q.y + q.z * q.w); m[4] = 1 - two_s * (q.x * q.x + q.z * q.z); m[5] = two_s * (q.y * q.z - q.x * q.w);
+    m[6] = two_s * (q.x * q.z - q.y * q.w); m[7] = two_s * (q.y * q.z + q.x * q.w); m[8] = 1 - two_s * (q.x * q.x + q.y * q.y);
+}
+// rotate p by q: vector part of q * (0, p) * conj(q)
+EG_D void q_apply(Quat q, const float (&p)[3], float (&o)[3]) {
+    const Quat t = q_mul(q_mul(q, Quat{0.f, p[0], p[1], p[2]}), Quat{q.w, -q.x, -q.y, -q.z});
+    o[0] = t.x; o[1] = t.y; o[2] = t.z;
+}
+struct ConvertArgs {
+    const float* x;     // [B][T][198]: 22 x 3 normalised joint positions, then 22 x 6D rotations
+    const float* rec;   // [B][4] un-canonicalising rotation (w, x, y, z)
+    const float* jmin;  // [66]
+    const float* jmax;  // [66]
+    float* aa;          // [B][T][22][3]
+    float* root;        // [B][T][3]
+    float* head;        // [B][T][3]
+    int parents[22];
+    int head_idx, B, T;
+};
+EG_D Quat global_quat(const float* frame, int j, Quat rec) {
+    float m[9];
+    rot6d_rows(frame + 66 + 6 * j, m);
+    const Quat ori = q_std(q_mul(rec, mat_to_quat(m)));  // M:494-496
+    quat_to_mat(ori, m);                                 // M:505
+    return mat_to_quat(m);                               // quat_ik's own matrix -> quaternion
+}
+__global__ void k_convert_model_res(ConvertArgs a) {
+    const int64_t n = (int64_t)a.B * a.T * 22;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % 22);
+        const int64_t bt = i / 22;
+        const int b = (int)(bt / a.T);
+        const float* frame = a.x + bt * 198;
+        const Quat rec{a.rec[4 * b], a.rec[4 * b + 1], a.rec[4 * b + 2], a.rec[4 * b + 3]};
+        Quat loc = global_quat(frame, j, rec);
+        if (j > 0) {
+            const Quat gp = global_quat(frame, a.parents[j], rec);
+            loc = q_std(q_mul(Quat{gp.w, -gp.x, -gp.y, -gp.z}, loc));
+        }
+        float m[9];
+        quat_to_mat(loc, m);                      // quat_ik returns matrices ...
+        const Quat q = mat_to_quat(m);            // ... and matrix_to_axis_angle goes back through the quaternion
+        const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+        const float half = atan2f(nrm, q.w), ang = 2.0f * half;
+        const float s = fabsf(ang) < 1e-6f ? 0.5f - ang * ang / 48.0f : sinf(half) / ang;
+        float* o = a.aa + i * 3;
+        o[0] = q.x / s; o[1] = q.y / s; o[2] = q.z / s;
+        if (j == 0 || j == a.head_idx) {
+            float p[3], r[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float lo = a.jmin[3 * j + c], hi = a.jmax[3 * j + c];
+                p[c] = (frame[3 * j + c] + 1.0f) * 0.5f * (hi - lo) + lo;
+            }
+            q_apply(rec, p, r);
+            float* dst = (j == 0 ? a.root : a.head) + bt * 3;
+            dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- debug / test-only unpackers
 // fragment-tiled [Mp][N] -> fp32 [B][L][N] (drops the padding rows).
 __global__ void k_unpack_tiled(const __bf16* __restrict__ src, size_t plane, int N, int Lp, int L, int B,

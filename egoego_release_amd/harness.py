@@ -19,6 +19,8 @@ human_body_prior / SMPL-H are absent): parity for this tier is against oracle/ha
 independent numpy + scipy restatement, and is "unpinned" in the sense of SURVEY.md §8c.
 """
 import numpy as np
+import ctypes as C
+
 import torch
 
 from . import rotations as R
@@ -105,6 +107,24 @@ def convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_he
     (tensor or numpy)."""
     bs = all_res_list.shape[0]
     dev = all_res_list.device
+    jmin, jmax = getattr(ds, "global_jpos_min", None), getattr(ds, "global_jpos_max", None)
+    if all_res_list.is_cuda and jmin is not None and jmax is not None and all_res_list.shape[-1] == 198:
+        # one HIP kernel for the whole chain (egoego_convert_model_res); the torch expressions below are for CPU tensors
+        from . import _lib
+        lib = _lib.load()
+        x = all_res_list.to(torch.float32).contiguous()
+        n = x.shape[1]
+        rec = torch.as_tensor(recover_rot_quat).to(dev, torch.float32).reshape(bs, 4).contiguous()
+        lo = torch.as_tensor(jmin).to(dev, torch.float32).reshape(66).contiguous()
+        hi = torch.as_tensor(jmax).to(dev, torch.float32).reshape(66).contiguous()
+        aa = torch.empty(bs, n, 22, 3, device=dev, dtype=torch.float32)
+        root = torch.empty(bs, n, 3, device=dev, dtype=torch.float32)
+        head = torch.empty(bs, n, 3, device=dev, dtype=torch.float32)
+        par = (C.c_int32 * 22)(*[int(p) for p in parents])
+        _lib.check(lib.egoego_convert_model_res(x.data_ptr(), rec.data_ptr(), lo.data_ptr(), hi.data_ptr(), par, HEAD_IDX, bs, n,
+                                                aa.data_ptr(), root.data_ptr(), head.data_ptr(),
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return aa, root, head
     jpos = ds.de_normalize_jpos_min_max(all_res_list[:, :, :66].reshape(-1, 22, 3)).reshape(bs, -1, 22, 3)
     n = jpos.shape[1]
     rot6d = all_res_list[:, :, 66:].reshape(bs, n, 22, 6)

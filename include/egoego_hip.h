@@ -146,6 +146,17 @@ int egoego_ddim_loop(egoego_ctx* ctx, float* d_x, const float* d_x_cond, const i
 /* Replaces pytorch3d.transforms.rotation_6d_to_matrix at M:493: d_in [n][6] -> d_out [n][3][3]. */
 int egoego_rot6d_to_matrix(const float* d_in, float* d_out, int64_t n, void* stream);
 
+/* Replaces the post-loop conversion chain of one batch of windows: convert_model_res_to_data (M:469-525) with
+ * quat_ik (amass_diffusion_dataset.py:109-125) and the pytorch3d calls inside them (6D -> matrix -> quaternion,
+ * un-canonicalise, global -> local rotations, -> axis-angle; de-normalise and rotate the root / head positions).
+ *   d_x [B][T][198] normalised model output; d_rec_quat [B][4] (w,x,y,z) = recover_rot_quat (M:470);
+ *   d_jpos_min / d_jpos_max [66] = ds.global_jpos_min/max (amass_diffusion_dataset.py:379-392);
+ *   parents_host[22]: HOST array, parents_host[j] < j for j > 0 (the SMPL-H kintree, an input: SURVEY.md §8f #1);
+ *   d_aa [B][T][22][3] local axis-angle, d_root [B][T][3], d_head [B][T][3] (joint head_idx). */
+int egoego_convert_model_res(const float* d_x, const float* d_rec_quat, const float* d_jpos_min, const float* d_jpos_max,
+                             const int32_t* parents_host, int head_idx, int B, int T, float* d_aa, float* d_root, float* d_head,
+                             void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
  * kernel_id: EGOEGO_K_*.  begin() arms event pairs around every launch of that kernel;
  * end() synchronises the stream's events and returns the mean duration and launch count. */

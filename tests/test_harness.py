@@ -116,3 +116,26 @@ def test_sliding_window_hip_vs_oracle():
     d = Rot.from_rotvec(aa.reshape(-1, 3).cpu().numpy()) * Rot.from_rotvec(aa2.reshape(-1, 3)).inv()
     ang = np.abs(d.magnitude())
     assert np.median(ang) < 1e-3 and np.quantile(ang, 0.99) < 2e-2, (np.median(ang), np.quantile(ang, 0.99), ang.max())
+
+
+@pytest.mark.gpu
+def test_convert_model_res_hip_kernel_vs_torch_chain():
+    """egoego_convert_model_res (one HIP kernel for M:469-525 + quat_ik) against the torch chain of the same module run on
+    CPU tensors, which test_convert_model_res_to_data_cpu_vs_oracle pins to the numpy/scipy restatement."""
+    g = torch.Generator().manual_seed(31)
+    B, T = 3, 37
+    x = torch.rand(B, T, 198, generator=g) * 2 - 1
+    rec = torch.nn.functional.normalize(torch.randn(B, 4, generator=g), dim=-1).reshape(B, 1, 1, 4)
+    lo = -torch.rand(66, generator=g) - 0.5
+    hi = torch.rand(66, generator=g) + 0.5
+    ds = harness.SkeletonStats(lo, hi, torch.randn(22, 3, generator=g))
+    want = harness.convert_model_res_to_data(ds, x, rec)
+    got = harness.convert_model_res_to_data(ds, x.cuda(), rec.cuda())
+    for w, g_, name in zip(want, got, ("axis-angle", "root", "head")):
+        assert g_.is_cuda and g_.shape == w.shape
+        assert (g_.cpu() - w).abs().max().item() < 2e-5, name
+    # the same rotations, compared as matrices (insensitive to the axis-angle branch near pi)
+    from egoego_release_amd import rotations as R
+    assert (R.axis_angle_to_matrix(got[0].cpu()) - R.axis_angle_to_matrix(want[0])).abs().max().item() < 1e-5
+    with pytest.raises(Exception, match="earlier joint"):
+        harness.convert_model_res_to_data(ds, x.cuda(), rec.cuda(), parents=(-1,) + (5,) * 21)
