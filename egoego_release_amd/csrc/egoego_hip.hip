@@ -40,8 +40,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ------------------------------------------------------------------------------------ context
 struct LayerDev {
     __bf16 *w_qkv, *w_fc, *w_1, *w_2;  // fragment-tiled, 2 planes each
-    int8_t* w_qkv8;                    // i8x3 copy of w_qkv: 2 slices, rows tile-permuted for the sub-pass GEMM
-    int8_t* w_qkv8n;                   // the same in natural row order (attn_layer_i8_kernel)
+    int8_t* w_qkv8n;                   // i8x3 copy of w_qkv for attn_layer_i8_kernel: two slices, K in acc32 order
     float* s_qkv;                      // its row scales [3*HD]
     float *b_qkv, *b_fc, *ln1_g, *ln1_b, *b_1, *b_2, *ln2_g, *ln2_b;
 };
@@ -66,7 +65,6 @@ static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debu
 static int g_chunk = getenv("EGOEGO_CHUNK") ? atoi(getenv("EGOEGO_CHUNK")) : 0;  // windows per denoiser pass (0 = whole batch)
 static int g_fuse_attn = getenv("EGOEGO_FUSE_ATTN") ? atoi(getenv("EGOEGO_FUSE_ATTN")) : 1;  // 0: separate qkv + attention kernels
 static int g_fuse_tail = getenv("EGOEGO_FUSE_TAIL") ? atoi(getenv("EGOEGO_FUSE_TAIL")) : 1;  // 0: separate fc_ln / ffn1 / ffn2_ln kernels
-static int g_i8 = getenv("EGOEGO_I8") ? atoi(getenv("EGOEGO_I8")) : 0;  // experimental: int8-slice projections in the fused kernels
 static int g_i8_min_bh = getenv("EGOEGO_I8_MIN_BH") ? atoi(getenv("EGOEGO_I8_MIN_BH")) : 1;  // (window, head) pairs below which i8x3 falls back
 static int g_ablate = getenv("EGOEGO_ABLATE") ? atoi(getenv("EGOEGO_ABLATE")) : 0;  // perf-debug only
 
@@ -183,22 +181,6 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperan
     }
 }
 
-// The same kernel with the three projections computed from int8 slices (gemm.h "i8x3").  Q goes through
-// memory like K (the two int32 accumulators leave no room to keep it in registers).
-template <class C8, class C8V, class EQK, class EV, int KT>
-__global__ __launch_bounds__(C8::NT, C8::MINW) void qkv_attn_i8_kernel(GemmOperands g8, I8Scales sc, EQK eqk, EV ev, AttnArgs a, int H) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int bh = lid + a.bh0;
-    const int b = bh / H, h = bh - b * H;
-    i8_block<C8, EQK>(g8, sc, eqk, H + h, b, smem);      // K_h
-    i8_block<C8V, EV>(g8, sc, ev, 2 * H + h, b, smem);   // V_h
-    i8_block<C8, EQK>(g8, sc, eqk, h, b, smem);          // Q_h
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!(g8.ablate & 4)) attn_body<KT, 2, false>(a, bh, 0, smem);
-}
-
 // ------------------------------------------------------------------------------------ fused layer tail
 // One 8-wave workgroup takes 128 tokens through fc+residual+LayerNorm -> FFN-1+ReLU -> FFN-2+residual+LayerNorm.
 // Rows are independent, so the tile a phase reads is exactly the tile the previous phase of the SAME workgroup
@@ -258,9 +240,6 @@ template <int NP> using CfgB = GemmCfg<4, 2, 4, 2, (NP == 2 ? 1 : 2), NP, false,
 template <int NP> using CfgC = GemmCfg<2, 2, 4, 2, 2, NP, false>;
 // B for small batches: 512 x 64, 4 waves, 2-stage ring, two workgroups per CU — twice the blocks of B
 template <int NP> using CfgBs = GemmCfg<4, 2, 4, 1, (NP == 2 ? 1 : 2), NP, false, 2, 2>;
-// int8-slice sub-pass tile: 128 features x 128 tokens per block, 4 waves of 64f x 64t, 4-stage ring of 16 KiB
-using Cfg8 = GemmCfg<2, 2, 2, 2, 1, 2, false, 2, 4>;
-using Cfg8V = GemmCfg<2, 2, 2, 2, 1, 2, true, 2, 4>;
 template <int NP> using CfgQ = GemmCfg<8, 1, 1, 4, 1, NP, false, 2, 3>;  // fused kernel's Q projection: 256f x 32t per wave
 static const int BLK_A_F = 256, BLK_A_T = 128, BLK_B_T = 128;
 
@@ -339,7 +318,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         AttnArgs aa{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L, w0 * H};
         // the fused kernel has one workgroup per (window, head): below ~one workgroup per CU the unfused pair
         // (12 projection blocks per window) spreads the same work over more CUs
-        const bool i8 = NP == 2 && (g_i8 || c->cfg.precision == EGOEGO_PREC_I8X3);
+        const bool i8 = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;
         const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && nw * H >= (i8 ? g_i8_min_bh : 192);
         const bool fused_attn = attn_geom && !dbg_qkv;
         // the layer's output also as int8 slices when the next layer's attention kernel consumes them
@@ -353,32 +332,15 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 HIP_TRY(hipGetLastError());
             }
             ProfScope ps(c, EGOEGO_K_QKV, s);
-            if (g_i8 != 2) {
-                AttnLayerArgs al{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, L.b_qkv, w.hA8, w.h_plane, w.hA_scale, w.O, w.o_plane, HD / 16,
-                                 1.0f / sqrtf((float)c->cfg.d_k), H, g.L, w0 * H, g_ablate, g_trace};
-                static bool once = false;
-                if (!once) {
-                    HIP_TRY(allow_smem(attn_layer_i8_kernel, AL_SMEM_BYTES));
-                    once = true;
-                }
-                attn_layer_i8_kernel<<<dim3(nw * H), dim3(256), AL_SMEM_BYTES, s>>>(al);
-                HIP_TRY(hipGetLastError());
-            } else {
-                // operand strides are counted in bf16 elements (2 bytes) by the main loop
-                GemmOperands go{(const __bf16*)L.w_qkv8, (size_t)3 * HD * N_MODEL / 2, (const __bf16*)w.hA8, w.h_plane / 2, N_MODEL / 32, 0, 0, 0, g_ablate, nullptr};
-                I8Scales sc{L.s_qkv, w.hA_scale};
-                EpiQK<2> eqk8{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
-                EpiV<2> ev8{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
-                auto kern = qkv_attn_i8_kernel<Cfg8, Cfg8V, EpiQK<2>, EpiV<2>, 4>;
-                constexpr int smem = Cfg8::SMEM_BYTES > 2 * 4 * 2 * 4096 ? Cfg8::SMEM_BYTES : 2 * 4 * 2 * 4096;
-                static bool once = false;
-                if (!once) {
-                    HIP_TRY(allow_smem(kern, smem));
-                    once = true;
-                }
-                kern<<<dim3(nw * H), dim3(Cfg8::NT), smem, s>>>(go, sc, eqk8, ev8, aa, H);
-                HIP_TRY(hipGetLastError());
+            AttnLayerArgs al{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, L.b_qkv, w.hA8, w.h_plane, w.hA_scale, w.O, w.o_plane, HD / 16,
+                             1.0f / sqrtf((float)c->cfg.d_k), H, g.L, w0 * H, g_ablate, g_trace};
+            static bool once = false;
+            if (!once) {
+                HIP_TRY(allow_smem(attn_layer_i8_kernel, AL_SMEM_BYTES));
+                once = true;
             }
+            attn_layer_i8_kernel<<<dim3(nw * H), dim3(256), AL_SMEM_BYTES, s>>>(al);
+            HIP_TRY(hipGetLastError());
         } else if (fused_attn) {
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)
             ProfScope ps(c, EGOEGO_K_QKV, s);
@@ -647,15 +609,11 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
         if ((r = pack_weight(lw.w_q, HD, N_MODEL, N_MODEL, 0, L.w_qkv, qkv_plane, N_MODEL / 16, 0, 0, s))) return r;
         if ((r = pack_weight(lw.w_k, HD, N_MODEL, N_MODEL, 0, L.w_qkv, qkv_plane, N_MODEL / 16, HD, 0, s))) return r;
         if ((r = pack_weight(lw.w_v, HD, N_MODEL, N_MODEL, 0, L.w_qkv, qkv_plane, N_MODEL / 16, 2 * HD, 0, s))) return r;
-        if ((r = dev_alloc(c, (void**)&L.w_qkv8, 2 * qkv_plane, false, s))) return r;
         if ((r = dev_alloc(c, (void**)&L.s_qkv, sizeof(float) * 3 * HD, false, s))) return r;
         if ((r = dev_alloc(c, (void**)&L.w_qkv8n, 2 * qkv_plane, false, s))) return r;
-        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_q, N_MODEL, N_MODEL, L.w_qkv8n, qkv_plane, L.s_qkv, 0, 0);
-        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_k, N_MODEL, N_MODEL, L.w_qkv8n, qkv_plane, L.s_qkv, 0, HD);
-        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_v, N_MODEL, N_MODEL, L.w_qkv8n, qkv_plane, L.s_qkv, 0, 2 * HD);
-        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_q, N_MODEL, N_MODEL, L.w_qkv8, qkv_plane, L.s_qkv, 2, 0);
-        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_k, N_MODEL, N_MODEL, L.w_qkv8, qkv_plane, L.s_qkv, 2, HD);
-        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_v, N_MODEL, N_MODEL, L.w_qkv8, qkv_plane, L.s_qkv, 2, 2 * HD);
+        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_q, N_MODEL, N_MODEL, L.w_qkv8n, qkv_plane, L.s_qkv, 0);
+        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_k, N_MODEL, N_MODEL, L.w_qkv8n, qkv_plane, L.s_qkv, HD);
+        k_pack_rows_i8<<<HD, 256, 0, s>>>(lw.w_v, N_MODEL, N_MODEL, L.w_qkv8n, qkv_plane, L.s_qkv, 2 * HD);
         HIP_TRY(hipGetLastError());
         if ((r = dev_alloc(c, (void**)&L.b_qkv, sizeof(float) * 3 * HD, false, s))) return r;
         HIP_TRY(hipMemcpyAsync(L.b_qkv, lw.b_q, sizeof(float) * HD, hipMemcpyDeviceToDevice, s));

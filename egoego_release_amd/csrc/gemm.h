@@ -346,20 +346,14 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_kernel(GemmOperands g,
         GemmBody<CV, EpiV>::run(g, ev, fblk, tblk, smem);
 }
 
-// ------------------------------------------------------------------------------------ int8-slice blocks
+// ------------------------------------------------------------------------------------ int8-slice helpers
 // "i8x3": both operands are integers q = rint(v / scale) with |q| <= 32639 (one scale per token row, one per
 // weight row), stored as two int8 slices q = 256*s1 + s2.  A product costs three v_mfma_i32_32x32x32_i8
 // (s1*s1 into one int32 accumulator, s1*s2 + s2*s1 into a second; s2*s2 is dropped like lo*lo in split-bf16),
-// each covering K = 32: half the matrix-pipe time of the three bf16 MFMAs.  Two accumulators per tile double
-// the register cost, so a wave's 128f x 64t tile is produced in two sub-passes over 64-feature halves; the
-// weight rows are stored tile-permuted (k_pack_rows_i8) so that each half is a contiguous block.
-struct I8Scales {
-    const float* w;  // [N]  weight row scales, original row order
-    const float* a;  // [Mp] token row scales
-};
+// each covering K = 32: half the matrix-pipe time of the three bf16 MFMAs, on operands of half the bytes.
 
 // 256 * H + M in one int32: |sum| <= K * (127*127*256 + 2*127*128), which fits for K <= 512 — every contraction
-// here (d_model = 512, d_k = 256, <= 224 keys).  The result is the integer dot product / 256.
+// here (d_model = 512, d_k = 256, <= 128 keys).  The result is the integer dot product / 256.
 EG_D int i8_combine(int h, int m) { return (h << 8) + m; }
 
 // int32 pair -> fp32, swapped accumulator (lane owns a token)
@@ -370,8 +364,7 @@ EG_D void i8_dequant(const I8Acc& q, f32x16& o, const float* sw8, float sa) {
         const float4 w4 = *(const float4*)(sw8 + 8 * g);  // features 8g + 4hf + (0..3); sw8 already includes 4*hf
         const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sa256 * ws[c]);
+        for (int c = 0; c < 4; ++c) o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sa256 * ws[c]);
     }
 }
 // un-swapped accumulator (lane owns a feature, registers walk tokens)
@@ -382,40 +375,7 @@ EG_D void i8_dequant_rows(const I8Acc& q, f32x16& o, float sw, const float* sa8)
         const float4 a4 = *(const float4*)(sa8 + 8 * g);
         const float as[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sw256 * as[c]);
-    }
-}
-
-// One (feature block, token block) of C8::BF*2 features: two sub-passes, each followed by the bf16 path's epilogue
-// on its half.  fblk counts blocks of 2*C8::BF original rows.
-template <class C8, class Epi>
-__device__ __forceinline__ void i8_block(const GemmOperands& g8, const I8Scales& sc, const Epi& epi, int fblk, int tblk, char* smem) {
-    static_assert(C8::FT == 2 && C8::TT == 2 && C8::NP == 2, "sub-pass tile is 64 features x 64 tokens per wave");
-    const int wave = wave_id_uniform();
-    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
-    const int wf = wave % C8::NWF, wt = wave / C8::NWF;
-    const int t0 = (tblk * C8::AT + wt * C8::TT) * 32;
-#pragma unroll 1
-    for (int fh = 0; fh < 2; ++fh) {
-        I8Acc q[2][2];
-        GemmBody<C8, Epi>::mainloop(g8, 2 * fblk + fh, tblk, smem, q);
-        const int f0 = ((fblk * C8::NWF + wf) * 4 + fh * 2) * 32;  // original feature index of this half
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (C8::ACT_ROWS)
-                    i8_dequant_rows(q[i][j], acc[i][j], sc.w[f0 + i * 32 + col], sc.a + t0 + j * 32 + 4 * hf);
-                else
-                    i8_dequant(q[i][j], acc[i][j], sc.w + f0 + i * 32 + 4 * hf, sc.a[t0 + j * 32 + col]);
-            }
-        if (g8.ablate & 2) {
-            if (acc[0][0][0] == 123.456f) *(float*)smem = acc[1][1][7];
-            continue;
-        }
-        epi.template run<2, 2>(acc, f0, t0, lane, wf, wt, smem);
+        for (int c = 0; c < 4; ++c) o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sw256 * as[c]);
     }
 }
 

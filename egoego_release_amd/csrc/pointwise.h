@@ -25,12 +25,10 @@ __global__ void k_pack_rows(const float* __restrict__ src, int R, int ncols, int
     }
 }
 
-// fp32 weights [R][K] -> int8 slices (common.h "i8x3"), one scale per output row.  One block per row.
-// Rows are stored tile-permuted for the sub-pass GEMM: inside every group of 4*nwf row tiles, original tile
-// wf*4 + 2*fh + i goes to fh*(2*nwf) + wf*2 + i, so that "feature half fh" of all waves is one contiguous block.
-// The K axis is stored in accumulator order (acc32), matching the activation planes.
+// fp32 weights [R][K] -> int8 slices (common.h "i8x3"), one scale per output row.  One block per row (row r0 + blockIdx.x
+// of the destination).  The K axis is stored in accumulator order (acc32), matching the activation planes.
 __global__ __launch_bounds__(256) void k_pack_rows_i8(const float* __restrict__ src, int K, int ld, int8_t* dst, size_t plane,
-                                                      float* __restrict__ scales, int nwf, int r0) {
+                                                      float* __restrict__ scales, int r0) {
     __shared__ float red[256];
     const int r = blockIdx.x + r0;
     const float* row = src + (size_t)blockIdx.x * ld;
@@ -45,13 +43,10 @@ __global__ __launch_bounds__(256) void k_pack_rows_i8(const float* __restrict__ 
     mx = red[0];
     const float inv = mx > 0.f ? I8_QMAX / mx : 0.f;
     if (threadIdx.x == 0) scales[r] = mx > 0.f ? mx / I8_QMAX : 0.f;
-    const int tile = r >> 5, grp = nwf ? 4 * nwf : 4, t = tile % grp;
-    const int wf = t >> 2, fh = (t >> 1) & 1, i = t & 1;
-    const int rp = nwf ? ((tile - t) + fh * (2 * nwf) + wf * 2 + i) * 32 + (r & 31) : r;  // nwf = 0: natural row order
     for (int k = threadIdx.x; k < K; k += 256) {
         const int q = (int)rintf(row[k] * inv);
         const int a1 = (q + 128) >> 8, a2 = q - (a1 << 8);
-        const size_t idx = tiled_index_i8(rp, acc32(k), K >> 5);
+        const size_t idx = tiled_index_i8(r, acc32(k), K >> 5);
         dst[idx] = (int8_t)a1;
         dst[plane + idx] = (int8_t)a2;
     }

@@ -155,3 +155,71 @@ def test_xcd_remap_is_bijective():
         return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
     for n in (1, 7, 8, 9, 24, 100, 6144, 6151):
         assert sorted(remap(b, n) for b in range(n)) == list(range(n))
+
+
+# ------------------------------------------------------------------ int8 slices ("i8x3", csrc/common.h, gemm.h)
+QMAX = 32639
+
+
+def acc32(f):
+    r = f & 31
+    return (f & ~31) | (((r >> 2) & 1) << 4) | ((r >> 3) << 2) | (r & 3)
+
+
+def tiled_index_i8(r, k, K32):
+    return ((((r >> 5) * K32 + (k >> 5)) * 2 + ((k >> 4) & 1)) << 9) + ((r & 31) << 4) + (k & 15)
+
+
+def slices(v, scale_inv):
+    """quant16: q = rint(v * inv) through the float adder (magic number), low byte = s2, byte 1 of q + 128 = s1."""
+    u = (np.float32(v) * np.float32(scale_inv) + np.float32(12582912.0)).astype(np.float32).view(np.uint32)
+    s2 = (u & 0xFF).astype(np.uint8).view(np.int8)
+    s1 = (((u + np.uint32(128)) >> 8) & 0xFF).astype(np.uint8).view(np.int8)
+    return s1.astype(np.int64), s2.astype(np.int64)
+
+
+def test_int8_slices_reconstruct_the_16_bit_integer():
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal(4096).astype(np.float32)
+    v[:4] = [0.0, v.max(), -np.abs(v).max(), np.abs(v).max()]
+    inv = np.float32(QMAX) / np.abs(v).max()
+    s1, s2 = slices(v, inv)
+    q = np.rint(v.astype(np.float64) * np.float64(inv))
+    assert np.abs(256 * s1 + s2 - q).max() <= 1  # fma rounds once, rint(float product) twice: at most one unit apart
+    assert np.abs(s1).max() <= 127 and s2.min() >= -128 and s2.max() <= 127
+    # the two-accumulator product: 256*H + M fits int32 for K <= 512 and reproduces the dropped-s2*s2 product
+    K = 512
+    worst = K * (127 * 127 * 256 + 2 * 127 * 128)
+    assert worst < 2 ** 31
+    a1, a2 = slices(rng.standard_normal(K).astype(np.float32), np.float32(9000.0))
+    w1, w2 = slices(rng.standard_normal(K).astype(np.float32), np.float32(9000.0))
+    H, M = int((a1 * w1).sum()), int((a1 * w2 + a2 * w1).sum())
+    exact = int(((256 * a1 + a2) * (256 * w1 + w2)).sum())
+    assert 256 * (256 * H + M) == exact - int((a2 * w2).sum())
+
+
+def test_acc32_order_and_int8_fragment_layout():
+    # acc32 permutes inside groups of 32 and sends accumulator register 4g + c of lane half hf (feature 8g + 4hf + c) to byte 16hf + 4g + c
+    assert sorted(acc32(f) for f in range(64)) == list(range(64))
+    for hf in range(2):
+        for g in range(4):
+            for c in range(4):
+                assert acc32(32 + 8 * g + 4 * hf + c) == 32 + 16 * hf + 4 * g + c
+    # tiled_index_i8: bijection; a lane (row, half) of an MFMA fragment owns 16 consecutive bytes at 16 * lane
+    R, K = 64, 128
+    idx = np.array([[tiled_index_i8(r, k, K // 32) for k in range(K)] for r in range(R)])
+    assert sorted(idx.ravel()) == list(range(R * K))
+    for r in (0, 5, 37):
+        for kb in (0, 3):
+            for half in range(2):
+                base = idx[r, kb * 32 + half * 16]
+                assert base % 1024 == 16 * (half * 32 + (r & 31))
+                assert np.array_equal(idx[r, kb * 32 + half * 16: kb * 32 + half * 16 + 16], base + np.arange(16))
+    # a contraction is indifferent to the K order as long as both operands share it
+    rng = np.random.default_rng(1)
+    a, w = rng.integers(-127, 128, (4, 64)), rng.integers(-127, 128, (3, 64))
+    perm = np.array([acc32(k) for k in range(64)])
+    ap, wp = np.empty_like(a), np.empty_like(w)
+    ap[:, perm], wp[:, perm] = a, w
+    assert np.array_equal(a @ w.T, ap @ wp.T)
+
