@@ -302,11 +302,20 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
     const bool small_ln = tb_b < 200;  // fewer 128-token LayerNorm blocks than CUs: use the 64-token tile
     // --- embed: start_conv + time token + position embedding (TM:199-216)
+    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3 && g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn &&
+                         nw * c->H >= g_i8_min_bh;  // the first layer's attention kernel reads int8 rows
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
-        GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
-        EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B};
-        if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
+        if (i8_path && io.stop_stage != EGOEGO_DBG_EMBED) {
+            // 512-feature blocks: the epilogue sees whole rows and also writes them as int8 slices
+            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+            EpiEmbed<NP, 4, 128> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
+            if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+        } else {
+            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
+            EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, nullptr, 0, nullptr};
+            if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
+        }
     }
     if (io.stop_stage == EGOEGO_DBG_EMBED) return 0;
     for (int li = 0; li < c->cfg.n_dec_layers; ++li) {
@@ -325,7 +334,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         const bool q8_out = i8 && attn_geom && li + 1 < c->cfg.n_dec_layers;
         int8_t* const q8p = q8_out ? w.hA8 : nullptr;
         if (fused_attn && i8) {
-            if (li == 0) {  // later layers get their int8 rows from the previous layer's LayerNorm epilogue
+            if (li == 0 && !i8_path) {  // int8 rows normally come from the embed / previous LayerNorm epilogue; this is the debug-stop route
                 ProfScope ps(c, EGOEGO_K_EMBED, s);
                 k_quant_rows<<<rows / 32, 256, 0, s>>>(w.hA + (size_t)row0 * N_MODEL, w.h_plane, w.hA8 + (size_t)row0 * N_MODEL, w.h_plane,
                                                        w.hA_scale + row0);

@@ -661,7 +661,10 @@ struct EpiResLN {
 
 // start_conv bias + frozen position embedding, time token in row 0 of every window, zeros in the
 // padding rows (TM:199-216; M:122-123,133).  Row l of a window gets position id l + 1.
-template <int NP>
+// NWF / BT (optional): waves along the features and tokens per block of the launching tile.  When the block spans all
+// 512 features (NWF * FT * 32 == 512) and q8 is set, the rows are also written as int8 slices with one scale per row
+// (the i8x3 attention-layer kernel's operand), like the LayerNorm epilogues do for the later layers.
+template <int NP, int NWF = 0, int BT = 0>
 struct EpiEmbed {
     const float* bias;      // [512]
     const float* pe;        // [max_timesteps + 1][512]
@@ -670,9 +673,14 @@ struct EpiEmbed {
     __bf16* out;
     size_t out_plane;
     int Lp, T, B;
+    int8_t* q8;
+    size_t q8_plane;
+    float* q8_scale;
     template <int FT, int TT>
-    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem) const {
         const int hf = lane >> 5, col = lane & 31;
+        constexpr bool Q8 = NWF > 0 && NWF * FT * 32 == 512;
+        float* red = (float*)smem;  // [TT][NWF][BT] row maxima per wave (Q8 only)
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
@@ -680,6 +688,7 @@ struct EpiEmbed {
             const int kind = (b >= B || lw > T) ? 0 : (lw == 0 ? 1 : 2);
             const float* trow = (kind == 1) ? tt_table + (size_t)t_idx[b] * 512 : nullptr;
             const float* prow = (kind == 2) ? pe + (size_t)(lw + 1) * 512 : nullptr;
+            float amax = 0.f;
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -698,12 +707,46 @@ struct EpiEmbed {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) v[c] = (acc[i][j][8 * jj + c] + bb[c]) + pp[c];
                     }
+                    if (Q8) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            acc[i][j][8 * jj + c] = v[c];
+                            amax = fmaxf(amax, fabsf(v[c]));
+                        }
+                    }
                     u32x4 hi, lo;
                     split8(v, hi, lo);
                     const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
                     *(u32x4*)(out + idx) = hi;
                     if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
                 }
+            if (Q8 && q8) {
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                if (hf == 0) red[(j * NWF + wf) * BT + (wt * TT + j) * 32 + col] = amax;
+            }
+        }
+        if (Q8 && q8) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                const int m = t0 + j * 32 + col;
+                float rmax = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red[(j * NWF + w) * BT + (wt * TT + j) * 32 + col]);
+                const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+                if (wf == 0 && hf == 0) q8_scale[m] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                    u32x4 s1, s2;
+                    quant16(v, inv, s1, s2);
+                    const size_t idx = acc_slot_i8(m, f0 + i * 32, hf, 16);
+                    *(u32x4*)(q8 + idx) = s1;
+                    *(u32x4*)(q8 + q8_plane + idx) = s2;
+                }
+            }
         }
     }
 };
