@@ -39,7 +39,7 @@ struct AttnLayerArgs {
 using AL8K = GemmCfg<4, 2, 2, 2, 1, 2, false, 1, 3>;
 using AL8V = GemmCfg<4, 2, 2, 2, 1, 2, true, 1, 3>;
 using AL8Q = GemmCfg<8, 1, 1, 4, 1, 2, false, 1, 3>;
-static constexpr int AL_KV_BYTES = 65536, AL_SLICE = 32768, AL_MISC_BYTES = 4096;
+static constexpr int AL_KV_BYTES = 65536, AL_SLICE = 32768, AL_MISC_BYTES = 12288;
 static constexpr int AL_SMEM_BYTES = AL_KV_BYTES + AL_MISC_BYTES + AL8K::SMEM_BYTES;
 struct NoEpi {};
 
@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
     float* sk = (float*)(smem + AL_KV_BYTES);      // [128] key row scales
     float* sv = sk + 128;                          // [256] V column scales
     float* red = sv + 256;                         // [512] cross-wave maxima
+    // this (window, head)'s epilogue parameters, staged once: a lone wave per SIMD cannot hide their L2 latency
+    float* p_ws = red + 512;                       // [3][256] weight row scales of Q_h, K_h, V_h
+    float* p_b = p_ws + 768;                       // [3][256] biases
+    float* p_hs = p_b + 768;                       // [128] row scales of the window's int8 input rows
     char* ring = smem + AL_KV_BYTES + AL_MISC_BYTES;
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the H heads of a window share an XCD (and its L2)
     const int bh = lid + a.bh0;
@@ -59,7 +63,6 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
     const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
     // operand strides are counted in bf16 elements (2 bytes) by the main loop; K16 counts 32-wide k blocks here
     const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0, 0, nullptr};
-    const int HD = a.H * 256;
     unsigned long long* tr = a.trace ? a.trace + 131072 + (size_t)blockIdx.x * 16 : nullptr;
     auto mark = [&](int i) {
         if (tr && threadIdx.x == 0) {
@@ -68,6 +71,15 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
         }
     };
     mark(0);
+    {
+        const int HD = a.H * 256;
+        for (int i = threadIdx.x; i < 768; i += 256) {
+            const int src = (i >> 8) * HD + h * 256 + (i & 255);
+            p_ws[i] = a.w_scale[src];
+            p_b[i] = a.bias[src];
+        }
+        if (threadIdx.x < 128) p_hs[threadIdx.x] = a.h_scale[b * 128 + threadIdx.x];
+    }  // visible after the first barrier of the K projection's main loop
 
     // ---- 1. K_h -> LDS ------------------------------------------------------------------------------
     {
@@ -75,19 +87,19 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
         GemmBody<AL8K, NoEpi>::mainloop(g, a.H + h, b, ring, q);
         mark(1);
         const int wf = wave & 1, wt = wave >> 1;
-        const int f0 = HD + h * 256 + wf * 128;
-        const int t0 = b * 128 + wt * 64;
+        const int f0 = 256 + wf * 128;  // index into the staged parameters
+        const int t0 = wt * 64;
         f32x16 v[4][2];
         float amax[2] = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float sa = a.h_scale[t0 + j * 32 + col];
+            const float sa = p_hs[t0 + j * 32 + col];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                i8_dequant(q[i][j], v[i][j], a.w_scale + f0 + i * 32 + 4 * hf, sa);
+                i8_dequant(q[i][j], v[i][j], p_ws + f0 + i * 32 + 4 * hf, sa);
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const float4 b4 = *(const float4*)(a.bias + f0 + i * 32 + 8 * gq + 4 * hf);
+                    const float4 b4 = *(const float4*)(p_b + f0 + i * 32 + 8 * gq + 4 * hf);
                     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -128,16 +140,16 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
         I8Acc q[8][1];
         GemmBody<AL8Q, NoEpi>::mainloop(g, h, b, ring, q);
         mark(3);
-        const int f0 = h * 256;
-        const float sa = a.h_scale[b * 128 + wave * 32 + col];
+        const int f0 = 0;  // index into the staged parameters
+        const float sa = p_hs[wave * 32 + col];
         f32x16 v[8];
         float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            i8_dequant(q[i][0], v[i], a.w_scale + f0 + i * 32 + 4 * hf, sa);
+            i8_dequant(q[i][0], v[i], p_ws + f0 + i * 32 + 4 * hf, sa);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const float4 b4 = *(const float4*)(a.bias + f0 + i * 32 + 8 * gq + 4 * hf);
+                const float4 b4 = *(const float4*)(p_b + f0 + i * 32 + 8 * gq + 4 * hf);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -232,17 +244,17 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
         GemmBody<AL8V, NoEpi>::mainloop(g, 2 * a.H + h, b, ring, q);
         mark(6);
         const int wf = wave & 1, wt = wave >> 1;
-        const int f0 = 2 * HD + h * 256 + wf * 128;
-        const int t0 = b * 128 + wt * 64;
+        const int f0 = 512 + wf * 128;  // index into the staged parameters
+        const int t0 = wt * 64;
         f32x16 v[4][2];
         float amax[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float sw = a.w_scale[f0 + i * 32 + col], bf = a.bias[f0 + i * 32 + col];
+            const float sw = p_ws[f0 + i * 32 + col], bf = p_b[f0 + i * 32 + col];
             amax[i] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                i8_dequant_rows(q[i][j], v[i][j], sw, a.h_scale + t0 + j * 32 + 4 * hf);
+                i8_dequant_rows(q[i][j], v[i][j], sw, p_hs + t0 + j * 32 + 4 * hf);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     v[i][j][r] += bf;
