@@ -16,6 +16,7 @@ B, T = 256, 120
 cfg = ModelConfig(max_timesteps=T + 1)
 m = CondGaussianDiffusion(**cfg.ctor_kwargs())
 m.load_state_dict(make_weights(cfg, 0), strict=False)
+m.hip_precision = _lib.PREC_BF16X3
 m = m.cuda()
 eng = m.hip_engine()
 lib = _lib.load()

@@ -16,7 +16,7 @@ from oracle import egoego_oracle as O
 
 def main():
     B, T = int(os.environ.get("DIAG_B", 2)), int(os.environ.get("DIAG_T", 120))
-    prec = int(os.environ.get("DIAG_PREC", 3))
+    prec = int(os.environ.get("DIAG_PREC", 8))
     cfg = ModelConfig(max_timesteps=T + 1)
     sd = make_weights(cfg, 0)
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
