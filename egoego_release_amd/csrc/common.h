@@ -1,4 +1,4 @@
-// common.h — types, the fragment-tiled split-bf16 layout, and small device helpers.
+// common.h — types, the fragment-tiled split-bf16 and int8-slice layouts, and small device helpers.
 //
 // Data layout used for every intermediate tensor and every weight (gfx950-first design):
 //

@@ -1,4 +1,4 @@
-// gemm.h — split-bf16 MFMA GEMM over fragment-tiled operands, with fused epilogues.
+// gemm.h — MFMA GEMM over fragment-tiled operands (split-bf16, or int8 slices), with fused epilogues.
 //
 // Every Linear / Conv1d(k=1) of the denoiser (TM:45-47,55,102-103,179; M:102) is
 //     out[token][feature] = sum_k act[token][k] * W[feature][k]  (+ bias, + fused tail)
@@ -9,14 +9,15 @@
 // features in groups of 4 consecutive ones.  Consequences:
 //   * LayerNorm's reduction over features is in-lane (+1 cross-half shuffle, + LDS across the
 //     waves that split the feature dimension) — no 32-lane butterflies;
-//   * epilogues store 8 contiguous bytes (4 bf16) per lane straight into the next kernel's
-//     fragment-tiled operand;
+//   * epilogues store 16 contiguous bytes per lane (8 bf16 of one plane, or 16 int8 of one slice) straight into
+//     the next kernel's fragment-tiled operand, whose K axis is kept in accumulator order (common.h);
 //   * the V projection alone is issued un-swapped (ACT_ROWS) so that V lands transposed and
 //     key-permuted exactly as the PV MFMA of attention.h consumes it.
 //
-// Pipeline: global -> registers (next stage, in flight during the MFMAs) -> LDS (double buffered),
-// one __syncthreads per stage.  With NP == 2 each fragment pair costs three MFMAs
-// (lo*hi, hi*lo, hi*hi).
+// Pipeline (GemmBody::mainloop): an LDS ring of NSTAGE stages filled by LDS-DMA (global_load_lds_dwordx4, no VGPR
+// staging), counted s_waitcnt vmcnt + one raw s_barrier per stage, fragments read from LDS one half-tile ahead of the
+// MFMAs that consume them.  With NP == 2 each fragment pair costs three MFMAs (lo*hi, hi*lo, hi*hi); the int8-slice
+// form (accumulator type I8Acc) issues s2*s1, s1*s2 into one int32 accumulator and s1*s1 into a second.
 #pragma once
 #include "common.h"
 
