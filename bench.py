@@ -207,7 +207,7 @@ def main():
             "launch_us": k_us, "launches": k_n, "share_of_step": 4 * k_us / (1e3 * el / K) / 1e3 if k_n else None,
             "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time measured inside the timed region; three "
                     "MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe utilisation is 3x this fraction. "
-                    "The main loops are bound by L2->LDS operand bandwidth, not by the pipe (DESIGN.md, tools/microbench/dma_bw.hip)."}
+                    "Under MFMA load the chip sustains ~2.0 GHz, i.e. ~4.1 POP/s int8 / ~1.9 PFLOP/s bf16 (tools/microbench/mfma_rate.hip); DESIGN.md section 6 has the breakdown."}
         tail_roof = {
             "bound": "mfma", "kernel": "layer_tail_kernel (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 128 tokens, split-bf16)",
             "achieved": tail_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (tail_ach / PEAK_BF16_TFLOPS) if tail_ach else None,

@@ -12,20 +12,20 @@
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, int PIECES>
-__global__ __launch_bounds__(512) void k(const char* src, size_t span, size_t wg_stride, int iters, unsigned* sink) {
+__global__ __launch_bounds__(512) void k(const char* src, unsigned span, size_t wg_stride, int iters, unsigned* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int nw = blockDim.x >> 6;
     const char* base = src + (size_t)blockIdx.x * wg_stride;
     char* lds = smem + wave * PIECES * 1024 * 2;  // two slots per wave
     u32x4 acc = {0, 0, 0, 0};
-    size_t off = (size_t)wave * PIECES * 1024;
+    unsigned off = wave * PIECES * 1024;  // 32-bit offsets and power-of-two spans: no 64-bit modulo on the streaming path
     for (int it = 0; it < iters; ++it) {
         char* dst = lds + (it & 1) * PIECES * 1024;
         u32x4 r[PIECES];
 #pragma unroll
         for (int p = 0; p < PIECES; ++p) {
-            const char* g = base + (off + (size_t)p * 1024) % span + lane * 16;
+            const char* g = base + ((off + p * 1024) & (span - 1)) + lane * 16;
             if (MODE == 0 || MODE == 3) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void k(const char* src, size_t span, size_t wg
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) acc ^= r[p];
         }
-        off += (size_t)nw * PIECES * 1024;
+        off += nw * PIECES * 1024;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512) void k(const char* src, size_t span, size_t wg
 }
 
 template <int MODE, int PIECES>
-static void run(const char* name, int nw, size_t span, bool priv, const char* buf, unsigned* sink) {
+static void run(const char* name, int nw, unsigned span, bool priv, const char* buf, unsigned* sink) {
     const int iters = 2000, grid = 256;
     const size_t lds = 100 * 1024;
     hipFuncSetAttribute((const void*)k<MODE, PIECES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -68,7 +68,7 @@ static void run(const char* name, int nw, size_t span, bool priv, const char* bu
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double)grid * nw * iters * PIECES * 1024;
-    printf("%-28s waves %d pieces %d span %6zu KiB %s: %7.2f TB/s  (%.1f B/clk/CU at 2.0 GHz)\n", name, nw, PIECES, span >> 10,
+    printf("%-28s waves %d pieces %d span %6u KiB %s: %7.2f TB/s  (%.1f B/clk/CU at 2.0 GHz)\n", name, nw, PIECES, span >> 10,
            priv ? "private" : "shared ", bytes / ms / 1e9, bytes / ms / 1e9 * 1e12 / 256 / 2.0e9 / 1e0 / 1e0 * 1e-0 / 1.0 / 1.0 * 1.0 / 1e0);
 }
 

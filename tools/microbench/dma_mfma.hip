@@ -8,7 +8,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int NM, int NP, bool DO_MFMA, bool DO_DMA, int KIND, int STAG>
-__global__ __launch_bounds__(512) void k(const char* src, size_t span, int iters, float* sink) {
+__global__ __launch_bounds__(512) void k(const char* src, unsigned span, int iters, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int nw = blockDim.x >> 6;
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(512) void k(const char* src, size_t span, int iters
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     bf16x8 a, b;
     for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(lane + e); b[e] = (__bf16)(float)(lane - e); }
-    size_t off = (size_t)wave * NP * 1024;
+    unsigned off = wave * NP * 1024;  // 32-bit offsets and a power-of-two span: no 64-bit modulo on the streaming path
     for (int it = 0; it < iters; ++it) {
         char* dst = lds + (it & 1) * NP * 1024;
         // STAG 0: piece p right after MFMA p (every wave at the same point of the step)
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(512) void k(const char* src, size_t span, int iters
                 if (mm % SPREAD == 0 && mm / SPREAD < NP) {
                     const int p = mm / SPREAD;
                     __builtin_amdgcn_sched_barrier(0);
-                    const char* g = src + (off + (size_t)p * 1024) % span + lane * 16;
+                    const char* g = src + ((off + p * 1024) & (span - 1)) + lane * 16;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512) void k(const char* src, size_t span, int iters
         }
         if (DO_DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
         __builtin_amdgcn_s_barrier();
-        off += (size_t)nw * NP * 1024;
+        off += nw * NP * 1024;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float s = 0.f;
@@ -57,9 +57,9 @@ static float run(int nw, const char* buf, float* sink) {
     (void)hipFuncSetAttribute((const void*)k<NM, NP, M, D, KIND, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    k<NM, NP, M, D, KIND, STAG><<<256, nw * 64, lds>>>(buf, 4 << 20, 50, sink);
+    k<NM, NP, M, D, KIND, STAG><<<256, nw * 64, lds>>>(buf, 4u << 20, 50, sink);
     (void)hipEventRecord(e0);
-    k<NM, NP, M, D, KIND, STAG><<<256, nw * 64, lds>>>(buf, 4 << 20, iters, sink);
+    k<NM, NP, M, D, KIND, STAG><<<256, nw * 64, lds>>>(buf, 4u << 20, iters, sink);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
