@@ -306,7 +306,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                          nw * c->H >= g_i8_min_bh;  // the first layer's attention kernel reads int8 rows
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
-        if (i8_path && io.stop_stage != EGOEGO_DBG_EMBED) {
+        if (i8_path) {
             // 512-feature blocks: the epilogue sees whole rows and also writes them as int8 slices
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, tb_b, t0_b, g_ablate, g_trace};
             EpiEmbed<NP, 4, 128> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
@@ -334,12 +334,6 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         const bool q8_out = i8 && attn_geom && li + 1 < c->cfg.n_dec_layers;
         int8_t* const q8p = q8_out ? w.hA8 : nullptr;
         if (fused_attn && i8) {
-            if (li == 0 && !i8_path) {  // int8 rows normally come from the embed / previous LayerNorm epilogue; this is the debug-stop route
-                ProfScope ps(c, EGOEGO_K_EMBED, s);
-                k_quant_rows<<<rows / 32, 256, 0, s>>>(w.hA + (size_t)row0 * N_MODEL, w.h_plane, w.hA8 + (size_t)row0 * N_MODEL, w.h_plane,
-                                                       w.hA_scale + row0);
-                HIP_TRY(hipGetLastError());
-            }
             ProfScope ps(c, EGOEGO_K_QKV, s);
             AttnLayerArgs al{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, L.b_qkv, w.hA8, w.h_plane, w.hA_scale, w.O, w.o_plane, HD / 16,
                              1.0f / sqrtf((float)c->cfg.d_k), H, g.L, w0 * H, g_ablate, g_trace};

@@ -52,43 +52,6 @@ __global__ __launch_bounds__(256) void k_pack_rows_i8(const float* __restrict__ 
     }
 }
 
-// Split-bf16 rows [Mp][512] (fragment-tiled, accumulator order) -> int8 slices + one scale per row.
-// One block per 32-row tile; thread (row, part) covers 4 of the tile's 32 (feature tile, lane half) slots.
-// A lane's 16 accumulator registers are two 8-element bf16 slots (jj = 0, 1) and one 16-byte int8 slot.
-__global__ __launch_bounds__(256) void k_quant_rows(const __bf16* __restrict__ src, size_t src_plane, int8_t* dst, size_t dst_plane,
-                                                    float* __restrict__ scales) {
-    __shared__ float red[8][32];
-    const int mt = blockIdx.x, row = threadIdx.x & 31, part = threadIdx.x >> 5;
-    float v[4][16];
-    float mx = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int sidx = part * 4 + q, ft = sidx >> 1, hf = sidx & 1;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const size_t idx = ((((size_t)mt * 32 + 2 * ft + jj) * 2 + hf) << 8) + row * 8;
-            unpack8(*(const u32x4*)(src + idx), *(const u32x4*)(src + src_plane + idx), &v[q][8 * jj]);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(v[q][e]));
-    }
-    red[part][row] = mx;
-    __syncthreads();
-#pragma unroll
-    for (int p2 = 0; p2 < 8; ++p2) mx = fmaxf(mx, red[p2][row]);
-    const float inv = mx > 0.f ? I8_QMAX / mx : 0.f;
-    if (part == 0) scales[mt * 32 + row] = mx > 0.f ? mx / I8_QMAX : 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int sidx = part * 4 + q, ft = sidx >> 1, hf = sidx & 1;
-        u32x4 s1, s2;
-        quant16(v[q], inv, s1, s2);
-        const size_t idx = acc_slot_i8(mt * 32 + row, ft * 32, hf, 16);
-        *(u32x4*)(dst + idx) = s1;
-        *(u32x4*)(dst + dst_plane + idx) = s2;
-    }
-}
-
 // Concatenate x and x_cond (M:232) into the embed GEMM's operand: window b occupies rows
 // b*Lp .. b*Lp+Lp-1; row 0 is the (input-less) time-token slot, rows 1..T the frames, the rest
 // padding.  Columns [0, D) = x, [DP, DP + D) = x_cond, everything else zero.  The WHOLE buffer is
