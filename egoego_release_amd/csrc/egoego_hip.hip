@@ -240,6 +240,12 @@ template <int NP> using CfgB = GemmCfg<4, 2, 4, 2, (NP == 2 ? 1 : 2), NP, false,
 template <int NP> using CfgC = GemmCfg<2, 2, 4, 2, 2, NP, false>;
 // B for small batches: 512 x 64, 4 waves, 2-stage ring, two workgroups per CU — twice the blocks of B
 template <int NP> using CfgBs = GemmCfg<4, 2, 4, 1, (NP == 2 ? 1 : 2), NP, false, 2, 2>;
+// Small grids (fewer workgroups than CUs at the tiles above): the same contractions on smaller tiles, so that more CUs
+// take part and each workgroup's k-loop carries less work per step.  Same k order per output element -> same numbers.
+template <int NP> using CfgBt = GemmCfg<4, 1, 4, 1, (NP == 2 ? 2 : 4), NP, false, 1, 2>;  // 512f x 32t, 4 waves
+template <int NP> using CfgAh = GemmCfg<2, 2, 2, 2, 1, NP, false, 2, 3>;                   // 128f x 128t, 4 waves
+template <int NP> using CfgC2 = GemmCfg<2, 2, 4, 1, 2, NP, false, 2, 2>;                   // 256f x 64t, 4 waves
+static const int SMALL_GRID = 160;  // workgroups
 template <int NP> using CfgQ = GemmCfg<8, 1, 1, 4, 1, NP, false, 2, 3>;  // fused kernel's Q projection: 256f x 32t per wave
 static const int BLK_A_F = 256, BLK_A_T = 128, BLK_B_T = 128;
 
@@ -309,8 +315,14 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         if (i8_path) {
             // 512-feature blocks: the epilogue sees whole rows and also writes them as int8 slices
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, tb_b, t0_b, g_ablate, g_trace};
-            EpiEmbed<NP, 4, 128> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
-            if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+            if (tb_b <= SMALL_GRID) {
+                GemmOperands gs{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
+                EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
+                if (int r = launch_gemm<CfgBs<NP>>(gs, e, s)) return r;
+            } else {
+                EpiEmbed<NP, 4, 128> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
+                if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
+            }
         } else {
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
             EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, nullptr, 0, nullptr};
@@ -404,8 +416,14 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
             if (small_ln) {
                 GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
-                EpiResLN<NP, 4, 64> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
-                if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
+                if (go.ntb <= SMALL_GRID) {
+                    GemmOperands gt{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 32, row0 / 32, g_ablate, g_trace};
+                    EpiResLN<NP, 4, 32> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+                    if (int r = launch_gemm<CfgBt<NP>>(gt, e, s)) return r;
+                } else {
+                    EpiResLN<NP, 4, 64> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+                    if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
+                }
             } else {
                 GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_trace};
                 EpiResLN<NP, 4, 128> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
@@ -418,7 +436,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             ProfScope ps(c, EGOEGO_K_FFN1, s);
             GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
             EpiTiled<true, NP> e{L.b_1, w.F, w.h_plane, N_MODEL / 16};
-            if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
+            if (go.nfb * go.ntb <= SMALL_GRID) {
+                go.nfb = N_MODEL / 128;
+                if (int r = launch_gemm<CfgAh<NP>>(go, e, s)) return r;
+            } else if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_FFN_HIDDEN) return 0;
         // --- FFN conv 2 + residual + LayerNorm (+ padding mask) (TM:111-114, 139)
@@ -426,8 +447,14 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             ProfScope ps(c, EGOEGO_K_FFN2_LN, s);
             if (small_ln) {
                 GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
-                EpiResLN<NP, 4, 64> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
-                if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
+                if (go.ntb <= SMALL_GRID) {
+                    GemmOperands gt{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 32, row0 / 32, g_ablate, g_trace};
+                    EpiResLN<NP, 4, 32> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                    if (int r = launch_gemm<CfgBt<NP>>(gt, e, s)) return r;
+                } else {
+                    EpiResLN<NP, 4, 64> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                    if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
+                }
             } else {
                 GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace};
                 EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
@@ -440,7 +467,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         ProfScope ps(c, EGOEGO_K_OUT, s);
         GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c, g_ablate, g_trace};
         EpiOut<NP> e{io.out};
-        if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
+        if (tb_c <= SMALL_GRID) {
+            GemmOperands gs{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
+            if (int r = launch_gemm<CfgC2<NP>>(gs, e, s)) return r;
+        } else if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
     }
     return 0;
 }
