@@ -65,7 +65,6 @@ static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debu
 static int g_chunk = getenv("EGOEGO_CHUNK") ? atoi(getenv("EGOEGO_CHUNK")) : 0;  // windows per denoiser pass (0 = whole batch)
 static int g_fuse_attn = getenv("EGOEGO_FUSE_ATTN") ? atoi(getenv("EGOEGO_FUSE_ATTN")) : 1;  // 0: separate qkv + attention kernels
 static int g_fuse_tail = getenv("EGOEGO_FUSE_TAIL") ? atoi(getenv("EGOEGO_FUSE_TAIL")) : 1;  // 0: separate fc_ln / ffn1 / ffn2_ln kernels
-static int g_i8_min_bh = getenv("EGOEGO_I8_MIN_BH") ? atoi(getenv("EGOEGO_I8_MIN_BH")) : 1;  // (window, head) pairs below which i8x3 falls back
 static int g_ablate = getenv("EGOEGO_ABLATE") ? atoi(getenv("EGOEGO_ABLATE")) : 0;  // perf-debug only
 
 struct Geometry {
@@ -308,8 +307,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
     const bool small_ln = tb_b < 200;  // fewer 128-token LayerNorm blocks than CUs: use the 64-token tile
     // --- embed: start_conv + time token + position embedding (TM:199-216)
-    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3 && g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn &&
-                         nw * c->H >= g_i8_min_bh;  // the first layer's attention kernel reads int8 rows
+    // i8x3: windows of 97..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
+    // layer reads the embed output as int8 rows
+    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3 && g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn;
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
         if (i8_path) {
@@ -340,7 +340,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // the fused kernel has one workgroup per (window, head): below ~one workgroup per CU the unfused pair
         // (12 projection blocks per window) spreads the same work over more CUs
         const bool i8 = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;
-        const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && nw * H >= (i8 ? g_i8_min_bh : 192);
+        const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && (i8 || nw * H >= 192);
         const bool fused_attn = attn_geom && !dbg_qkv;
         // the layer's output also as int8 slices when the next layer's attention kernel consumes them
         const bool q8_out = i8 && attn_geom && li + 1 < c->cfg.n_dec_layers;
