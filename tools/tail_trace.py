@@ -30,8 +30,8 @@ eng.debug_stage(x, xc, t, 1, "embed") if False else eng.denoise(x, xc, t)
 torch.cuda.synchronize()
 lib.egoego_debug_trace_buffer(None)
 raw = buf.cpu()
-nb = B * 128 // 128
-ph = [raw[p * 2048:p * 2048 + nb * 4].view(nb, 4)[:, :3].double() / 100.0 for p in range(3)]
+nb = B * 128 // 64
+ph = [raw[p * 4096:p * 4096 + nb * 4].view(nb, 4)[:, :3].double() / 100.0 for p in range(3)]
 t0 = ph[0][:, 0].min()
 print("kernel span %.1f us" % (ph[2][:, 2].max() - t0))
 for name, a in zip(("fc + LN", "FFN-1", "FFN-2 + LN"), ph):
