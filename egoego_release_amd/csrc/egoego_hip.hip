@@ -315,16 +315,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
         if (i8_path) {
-            // 512-feature blocks: the epilogue sees whole rows and also writes them as int8 slices
-            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, tb_b, t0_b, g_ablate, g_trace};
-            if (tb_b <= SMALL_GRID) {
-                GemmOperands gs{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
-                EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
-                if (int r = launch_gemm<CfgBs<NP>>(gs, e, s)) return r;
-            } else {
-                EpiEmbed<NP, 4, 128> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
-                if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
-            }
+            // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
+            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
+            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
+            if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
         } else {
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
             EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, nullptr, 0, nullptr};
