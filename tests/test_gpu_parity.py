@@ -240,10 +240,10 @@ def test_ddim_against_oracle_restatement(prec):
         m.hip_engine().ddim_loop_(xs.cuda(), xs.cuda(), [5, 7])
 
 
-@pytest.mark.parametrize("B,T,n_head,n_layers", [(1, 1, 4, 4), (3, 2, 4, 4), (5, 31, 4, 4), (3, 63, 4, 4), (2, 127, 4, 4),
+@pytest.mark.parametrize("B,T,n_head,n_layers", [(1, 1, 4, 4), (3, 2, 4, 4), (5, 31, 4, 4), (3, 63, 4, 4), (2, 95, 4, 4), (3, 96, 4, 4), (2, 127, 4, 4),
                                                   (2, 128, 4, 4), (1, 223, 4, 4), (2, 50, 2, 1), (2, 120, 8, 2)])
 def test_shape_edge_cases_against_oracle(B, T, n_head, n_layers, prec):
-    """Minimum window (T=1), every key-tile boundary (L = 32/64/128/129), the maximum supported window
+    """Minimum window (T=1), every key-tile boundary (L = 32/64/96/97/128/129; 97..128 is the i8x3 kernel's range), the maximum supported window
     (T=223), odd batches, and other head / layer counts than the shipped checkpoint's."""
     cfg = ModelConfig(max_timesteps=T + 1, n_head=n_head, n_dec_layers=n_layers)
     sd = make_weights(cfg, 3)
