@@ -44,7 +44,7 @@ class Schedule(C.Structure):
 
 EXPORTS = ["egoego_abi_version", "egoego_last_error", "egoego_ctx_create", "egoego_ctx_destroy",
            "egoego_load_weights", "egoego_load_schedule", "egoego_workspace_bytes", "egoego_denoise",
-           "egoego_p_sample", "egoego_sample_loop", "egoego_ddim_loop", "egoego_rot6d_to_matrix", "egoego_convert_model_res",
+           "egoego_p_sample", "egoego_sample_loop", "egoego_ddim_loop", "egoego_rot6d_to_matrix", "egoego_convert_model_res", "egoego_window_prefix", "egoego_window_condition",
            "egoego_profile_begin", "egoego_profile_end", "egoego_debug_stage"]
 
 _lib = None
@@ -80,6 +80,8 @@ def load():
     lib.egoego_ddim_loop.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, sz, vp]
     lib.egoego_rot6d_to_matrix.argtypes = [vp, vp, i64, vp]
     lib.egoego_convert_model_res.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, vp, vp, vp]
+    lib.egoego_window_condition.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.egoego_window_prefix.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int32), i32, i32, i32, i32, vp, vp]
     lib.egoego_profile_begin.argtypes = [vp, i32]
     lib.egoego_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]
     lib.egoego_debug_stage.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, vp, sz, vp]

@@ -863,6 +863,35 @@ int egoego_convert_model_res(const float* d_x, const float* d_rec_quat, const fl
     return 0;
 }
 
+int egoego_window_condition(const float* d_head_jpos, const float* d_head_jquat, const float* d_jpos_min, const float* d_jpos_max,
+                            int head_idx, int B, int Tw, float* d_x_start, float* d_recover_quat, void* stream) {
+    if (!d_head_jpos || !d_head_jquat || !d_jpos_min || !d_jpos_max || !d_x_start || !d_recover_quat) return fail(EGOEGO_E_INVALID, "null argument");
+    if (B < 1 || Tw < 1 || head_idx < 0 || head_idx >= 22) return fail(EGOEGO_E_INVALID, "bad shape (B=%d, Tw=%d, head_idx=%d)", B, Tw, head_idx);
+    CondArgs a{d_head_jpos, d_head_jquat, d_jpos_min, d_jpos_max, d_x_start, d_recover_quat, head_idx, B, Tw};
+    const int n = B * Tw;
+    k_window_condition<<<(n + 127) / 128, 128, 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int egoego_window_prefix(const float* d_aa, const float* d_root, const float* d_rest_offsets, const float* d_jpos_min,
+                         const float* d_jpos_max, const int32_t* parents_host, int head_idx, int B, int Tw, int n_last,
+                         float* d_prefix, void* stream) {
+    if (!d_aa || !d_root || !d_rest_offsets || !d_jpos_min || !d_jpos_max || !parents_host || !d_prefix)
+        return fail(EGOEGO_E_INVALID, "null argument");
+    if (B < 1 || Tw < 1 || n_last < 1 || n_last > Tw || head_idx < 0 || head_idx >= 22)
+        return fail(EGOEGO_E_INVALID, "bad shape (B=%d, Tw=%d, n_last=%d, head_idx=%d)", B, Tw, n_last, head_idx);
+    PrefixArgs a{d_aa, d_root, d_rest_offsets, d_jpos_min, d_jpos_max, d_prefix, {}, head_idx, B, Tw, n_last};
+    for (int j = 0; j < 22; ++j) {
+        a.parents[j] = j ? parents_host[j] : 0;
+        if (j > 0 && (a.parents[j] < 0 || a.parents[j] >= j)) return fail(EGOEGO_E_INVALID, "parents[%d] = %d is not an earlier joint", j, a.parents[j]);
+    }
+    const int n = B * n_last;
+    k_window_prefix<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 /* perf-debug only (not in the public header): per-block timestamps of every GEMM launch go to `buf`
  * ([grid][4] u64, overwritten by each launch); nullptr disables. */
 int egoego_debug_trace_buffer(unsigned long long* buf) {

@@ -268,6 +268,151 @@ __global__ void k_convert_model_res(ConvertArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- next-window condition
+// The tail of one sliding-window iteration (M:399-467): forward kinematics of the last n_last frames (fk_smpl,
+// amass_diffusion_dataset.py:265-293), re-canonicalisation about their first frame's head heading (rotate_at_frame,
+// lafan1/utils.py:111-137), min/max normalisation and the 6D rotation form -> the [B][n_last][198] rows that overwrite the
+// first frames of the next window after every diffusion step.  One thread per (window, frame); same operation order as the
+// torch chain in harness.py.
+struct PrefixArgs {
+    const float* aa;    // [B][Tw][22][3] local axis-angle
+    const float* root;  // [B][Tw][3]
+    const float* rest;  // [22][3] rest-pose offsets
+    const float* jmin;  // [66]
+    const float* jmax;  // [66]
+    float* out;         // [B][n_last][198]
+    int parents[22];
+    int head_idx, B, Tw, n_last;
+};
+EG_D Quat aa_to_quat_via_matrix(const float* a3) {
+    const float ang = sqrtf(a3[0] * a3[0] + a3[1] * a3[1] + a3[2] * a3[2]);
+    const float half = 0.5f * ang;
+    const float sc = fabsf(ang) < 1e-6f ? 0.5f - ang * ang / 48.0f : sinf(half) / ang;
+    float m[9];
+    quat_to_mat(Quat{cosf(half), a3[0] * sc, a3[1] * sc, a3[2] * sc}, m);  // axis_angle_to_matrix ...
+    return mat_to_quat(m);                                                   // ... then matrix_to_quaternion
+}
+// global rotations / positions of all 22 joints of one frame
+EG_D void fk_frame(const PrefixArgs& a, const float* aa, const float* root, Quat (&gq)[22], float (&gp)[22][3]) {
+    gq[0] = aa_to_quat_via_matrix(aa);
+    gp[0][0] = a.rest[0]; gp[0][1] = a.rest[1]; gp[0][2] = a.rest[2];
+    for (int j = 1; j < 22; ++j) {
+        const int p = a.parents[j];
+        const float off[3] = {a.rest[3 * j], a.rest[3 * j + 1], a.rest[3 * j + 2]};
+        float r[3];
+        q_apply(gq[p], off, r);
+        gp[j][0] = r[0] + gp[p][0]; gp[j][1] = r[1] + gp[p][1]; gp[j][2] = r[2] + gp[p][2];
+        gq[j] = q_std(q_mul(gq[p], aa_to_quat_via_matrix(aa + 3 * j)));
+    }
+    for (int j = 0; j < 22; ++j) {
+        gp[j][0] += root[0]; gp[j][1] += root[1]; gp[j][2] += root[2];
+    }
+}
+__global__ void k_window_prefix(PrefixArgs a) {
+    const int n = a.B * a.n_last;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int b = i / a.n_last, f = i % a.n_last;
+        const int fr0 = a.Tw - a.n_last, fr = fr0 + f;
+        Quat gq[22];
+        float gp[22][3];
+        // heading of the slice's first frame: rotate +x by its head rotation, drop z, normalise; yrot takes +x onto it
+        fk_frame(a, a.aa + ((size_t)b * a.Tw + fr0) * 66, a.root + ((size_t)b * a.Tw + fr0) * 3, gq, gp);
+        const Quat key = gq[a.head_idx];
+        const float tx = 0.f, ty = 2.0f * key.z, tz = -2.0f * key.y;  // t = 2 * cross(key.xyz, ex)
+        float fx = 1.0f + key.w * tx + (key.y * tz - key.z * ty);
+        float fy = key.w * ty + (key.z * tx - key.x * tz);
+        const float fn = sqrtf(fx * fx + fy * fy) + 1e-8f;
+        fx /= fn; fy /= fn;
+        // (|x||f| + x.f, x cross f) with x = (1,0,0), f = (fx, fy, 0)
+        Quat yrot{sqrtf(fx * fx + fy * fy) + fx, 0.f, 0.f, fy};
+        const float yn = sqrtf(yrot.w * yrot.w + yrot.z * yrot.z) + 1e-8f;
+        yrot.w /= yn; yrot.z /= yn;
+        const Quat inv{yrot.w, -yrot.x, -yrot.y, -yrot.z};
+        // t_move: the rotated head position of the first frame, z dropped (rotate_at_frame's own formula)
+        const float hp[3] = {gp[a.head_idx][0], gp[a.head_idx][1], gp[a.head_idx][2]};
+        const float ix = 2.0f * (inv.y * hp[2] - inv.z * hp[1]), iy = 2.0f * (inv.z * hp[0] - inv.x * hp[2]), iz = 2.0f * (inv.x * hp[1] - inv.y * hp[0]);
+        const float mvx = hp[0] + inv.w * ix + (inv.y * iz - inv.z * iy);
+        const float mvy = hp[1] + inv.w * iy + (inv.z * ix - inv.x * iz);
+        if (f != 0) fk_frame(a, a.aa + ((size_t)b * a.Tw + fr) * 66, a.root + ((size_t)b * a.Tw + fr) * 3, gq, gp);
+        float* o = a.out + (size_t)i * 198;
+        for (int j = 0; j < 22; ++j) {
+            float r[3];
+            q_apply(inv, gp[j], r);
+            r[0] -= mvx; r[1] -= mvy;
+            for (int c = 0; c < 3; ++c) {
+                const float lo = a.jmin[3 * j + c], hi = a.jmax[3 * j + c];
+                o[3 * j + c] = (r[c] - lo) / (hi - lo) * 2.0f - 1.0f;
+            }
+            float m[9];
+            quat_to_mat(q_std(q_mul(inv, gq[j])), m);
+            for (int c = 0; c < 6; ++c) o[66 + 6 * j + c] = m[c];  // first two rows
+        }
+    }
+}
+
+// ---------------------------------------------------------------- window condition
+// Head of one sliding-window iteration (M:355-378): the window's head trajectory canonicalised about its first frame's heading
+// (rotate_at_frame, lafan1/utils.py:111-137; xy of the first frame moved to the origin), written into an otherwise zero
+// [B][Tw][198] x_start (head position dims 3*head_idx.., head 6D rotation dims 66 + 6*head_idx..), joint positions
+// min/max-normalised.  Also returns the un-canonicalising rotation per window.  One thread per (window, frame).
+struct CondArgs {
+    const float* jpos;   // [B][Tw][3] global head position
+    const float* jquat;  // [B][Tw][4] global head rotation (w, x, y, z)
+    const float* jmin;   // [66]
+    const float* jmax;   // [66]
+    float* x_start;      // [B][Tw][198]
+    float* recover;      // [B][4]
+    int head_idx, B, Tw;
+};
+EG_D void rotate_cross(Quat q, const float (&p)[3], float (&o)[3]) {  // p + w * t + cross(v, t), t = 2 cross(v, p)
+    const float tx = 2.0f * (q.y * p[2] - q.z * p[1]), ty = 2.0f * (q.z * p[0] - q.x * p[2]), tz = 2.0f * (q.x * p[1] - q.y * p[0]);
+    o[0] = p[0] + q.w * tx + (q.y * tz - q.z * ty);
+    o[1] = p[1] + q.w * ty + (q.z * tx - q.x * tz);
+    o[2] = p[2] + q.w * tz + (q.x * ty - q.y * tx);
+}
+EG_D Quat heading_quat(Quat key) {  // quaternion taking +x onto the xy-projection of key's forward direction
+    const float ex[3] = {1.f, 0.f, 0.f};
+    float f[3];
+    rotate_cross(key, ex, f);
+    const float fn = sqrtf(f[0] * f[0] + f[1] * f[1]) + 1e-8f;
+    const float fx = f[0] / fn, fy = f[1] / fn;
+    Quat y{sqrtf(fx * fx + fy * fy) + fx, 0.f, 0.f, fy};
+    const float yn = sqrtf(y.w * y.w + y.z * y.z) + 1e-8f;
+    y.w /= yn; y.z /= yn;
+    return y;
+}
+__global__ void k_window_condition(CondArgs a) {
+    const int n = a.B * a.Tw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int b = i / a.Tw, t = i % a.Tw;
+        const float* q0 = a.jquat + (size_t)b * a.Tw * 4;
+        const Quat yrot = heading_quat(Quat{q0[0], q0[1], q0[2], q0[3]});
+        const Quat inv{yrot.w, -yrot.x, -yrot.y, -yrot.z};
+        if (t == 0) {
+            float* r = a.recover + 4 * b;
+            r[0] = yrot.w; r[1] = yrot.x; r[2] = yrot.y; r[3] = yrot.z;
+        }
+        const float* p0 = a.jpos + (size_t)b * a.Tw * 3;
+        const float first[3] = {p0[0], p0[1], p0[2]}, cur[3] = {a.jpos[(size_t)i * 3], a.jpos[(size_t)i * 3 + 1], a.jpos[(size_t)i * 3 + 2]};
+        float m0[3], pos[3];
+        rotate_cross(inv, first, m0);
+        rotate_cross(inv, cur, pos);
+        pos[0] -= m0[0]; pos[1] -= m0[1];
+        const float* qq = a.jquat + (size_t)i * 4;
+        float m[9];
+        quat_to_mat(q_mul(inv, Quat{qq[0], qq[1], qq[2], qq[3]}), m);  // raw product, like rotate_at_frame
+        float* o = a.x_start + (size_t)i * 198;
+        for (int j = 0; j < 22; ++j)
+            for (int c = 0; c < 3; ++c) {
+                const float v = j == a.head_idx ? pos[c] : 0.f;
+                const float lo = a.jmin[3 * j + c], hi = a.jmax[3 * j + c];
+                o[3 * j + c] = (v - lo) / (hi - lo) * 2.0f - 1.0f;
+            }
+        for (int c = 66; c < 198; ++c) o[c] = 0.f;
+        for (int c = 0; c < 6; ++c) o[66 + 6 * a.head_idx + c] = m[c];
+    }
+}
+
 // ---------------------------------------------------------------- debug / test-only unpackers
 // fragment-tiled [Mp][N] -> fp32 [B][L][N] (drops the padding rows).
 __global__ void k_unpack_tiled(const __bf16* __restrict__ src, size_t plane, int N, int Lp, int L, int B,

@@ -138,6 +138,46 @@ def convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_he
     return R.matrix_to_axis_angle(local), root, head
 
 
+def _window_condition_hip(ds, head_jpos, head_jquat):
+    """egoego_window_condition (rotate_at_frame + x_start assembly + normalisation in one HIP kernel, M:355-378) for ROCm tensors
+    when `ds` exposes its min/max statistics as tensors; None otherwise.  Returns (x_start [B,Tw,198], recover [B,1,1,4])."""
+    jmin, jmax = getattr(ds, "global_jpos_min", None), getattr(ds, "global_jpos_max", None)
+    if not head_jpos.is_cuda or jmin is None or jmax is None:
+        return None
+    from . import _lib
+    lib = _lib.load()
+    dev = head_jpos.device
+    b, tw = head_jpos.shape[0], head_jpos.shape[1]
+    jp, jq = head_jpos.to(torch.float32).contiguous(), head_jquat.to(torch.float32).contiguous()
+    lo = torch.as_tensor(jmin).to(dev, torch.float32).reshape(66).contiguous()
+    hi = torch.as_tensor(jmax).to(dev, torch.float32).reshape(66).contiguous()
+    x_start = torch.empty(b, tw, 198, device=dev, dtype=torch.float32)
+    rec = torch.empty(b, 4, device=dev, dtype=torch.float32)
+    _lib.check(lib.egoego_window_condition(jp.data_ptr(), jq.data_ptr(), lo.data_ptr(), hi.data_ptr(), HEAD_IDX, b, tw, x_start.data_ptr(),
+                                           rec.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return x_start, rec.reshape(b, 1, 1, 4)
+
+
+def _window_prefix_hip(ds, aa, root, n_last, parents=SMPLH_PARENTS_22):
+    """egoego_window_prefix (one HIP kernel for fk_smpl + rotate_at_frame + normalisation + 6D, M:399-467) when the tensors
+    live on a ROCm device and `ds` exposes its statistics as tensors; None otherwise (the torch chain then runs)."""
+    rest, jmin, jmax = (getattr(ds, n, None) for n in ("rest_human_offsets", "global_jpos_min", "global_jpos_max"))
+    if not aa.is_cuda or rest is None or jmin is None or jmax is None or n_last < 1 or n_last > aa.shape[1]:
+        return None
+    from . import _lib
+    lib = _lib.load()
+    dev = aa.device
+    b, tw = aa.shape[0], aa.shape[1]
+    f32 = lambda t, n: torch.as_tensor(t).to(dev, torch.float32).reshape(n).contiguous()
+    aa_c, root_c = aa.to(torch.float32).contiguous(), root.to(torch.float32).contiguous()
+    rest_c, lo, hi = f32(rest, 66), f32(jmin, 66), f32(jmax, 66)
+    out = torch.empty(b, n_last, 198, device=dev, dtype=torch.float32)
+    par = (C.c_int32 * 22)(*[int(p) for p in parents])
+    _lib.check(lib.egoego_window_prefix(aa_c.data_ptr(), root_c.data_ptr(), rest_c.data_ptr(), lo.data_ptr(), hi.data_ptr(), par,
+                                        HEAD_IDX, b, tw, n_last, out.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out
+
+
 @torch.no_grad()
 def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos, global_head_jquat, cond_mask,
                                              noise=None, parents=SMPLH_PARENTS_22):
@@ -165,16 +205,19 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
             break
         cur_quat = jquat_all[:, t_idx:t_idx + seq_len]
         cur_jpos = jpos_all[:, t_idx:t_idx + seq_len]
-        al_trans, al_quat, recover = rotate_at_frame(cur_jpos, cur_quat, 0)
-        move0 = al_trans[:, 0:1, :].clone()
-        move0[:, :, 2] = 0
-        al_trans = al_trans - move0
-        al_6d = R.matrix_to_rotation_6d(R.quaternion_to_matrix(al_quat))
-        Tw = al_6d.shape[1]
-        x_start = torch.zeros(b, Tw, 198, device=device)
-        x_start[:, :, HEAD_IDX * 3:HEAD_IDX * 3 + 3] = al_trans.float()
-        x_start[:, :, 66 + HEAD_IDX * 6:66 + HEAD_IDX * 6 + 6] = al_6d.float()
-        x_start[:, :, :66] = ds.normalize_jpos_min_max(x_start[:, :, :66].reshape(-1, 22, 3)).reshape(b, -1, 66)
+        cond = _window_condition_hip(ds, cur_jpos, cur_quat)
+        if cond is not None:
+            x_start, recover = cond
+        else:
+            al_trans, al_quat, recover = rotate_at_frame(cur_jpos, cur_quat, 0)
+            move0 = al_trans[:, 0:1, :].clone()
+            move0[:, :, 2] = 0
+            al_trans = al_trans - move0
+            al_6d = R.matrix_to_rotation_6d(R.quaternion_to_matrix(al_quat))
+            x_start = torch.zeros(b, al_6d.shape[1], 198, device=device)
+            x_start[:, :, HEAD_IDX * 3:HEAD_IDX * 3 + 3] = al_trans.float()
+            x_start[:, :, 66 + HEAD_IDX * 6:66 + HEAD_IDX * 6 + 6] = al_6d.float()
+            x_start[:, :, :66] = ds.normalize_jpos_min_max(x_start[:, :, :66].reshape(-1, 22, 3)).reshape(b, -1, 66)
         cm = cond_mask[:, t_idx:t_idx + seq_len].to(device)
         cn = noise["cond"][w_idx].to(device) if noise is not None else torch.randn_like(x_start)
         x_cond = (x_start * (1.0 - cm) + cm * cn).float().contiguous()
@@ -198,6 +241,11 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
             whole_root = torch.cat((whole_root, root[:, seq_len - stride:]), dim=1)
             whole_head = torch.cat((whole_head, head[:, seq_len - stride:]), dim=1)
         # condition for the next window: the last `OVERLAP` frames, re-canonicalised and re-normalised
+        hip_prefix = _window_prefix_hip(ds, aa, root, seq_len - stride, parents)
+        if hip_prefix is not None:
+            prefix = hip_prefix
+            w_idx += 1
+            continue
         gq, gj = ds.fk_smpl(root.reshape(-1, 3), aa.reshape(-1, 22, 3))
         gq = gq.reshape(b, -1, 22, 4)[:, -seq_len + stride:]
         gj = gj.reshape(b, -1, 22, 3)[:, -seq_len + stride:]

@@ -157,6 +157,23 @@ int egoego_convert_model_res(const float* d_x, const float* d_rec_quat, const fl
                              const int32_t* parents_host, int head_idx, int B, int T, float* d_aa, float* d_root, float* d_head,
                              void* stream);
 
+/* The head condition of one sliding window (M:355-378): d_head_jpos [B][Tw][3] and d_head_jquat [B][Tw][4] (w,x,y,z) are
+ * canonicalised about the first frame's heading (rotate_at_frame, lafan1/utils.py:111-137; its xy moved to the origin) and
+ * written into an otherwise zero d_x_start [B][Tw][198] (position dims 3*head_idx.., 6D dims 66 + 6*head_idx..), joint
+ * positions min/max-normalised; d_recover_quat [B][4] receives the un-canonicalising rotation (recover_rot_quat of M:470). */
+int egoego_window_condition(const float* d_head_jpos, const float* d_head_jquat, const float* d_jpos_min, const float* d_jpos_max,
+                            int head_idx, int B, int Tw, float* d_x_start, float* d_recover_quat, void* stream);
+
+/* The condition of the next sliding window (M:399-467) from the current window's converted output: fk_smpl
+ * (amass_diffusion_dataset.py:265-293) over the last n_last frames, rotate_at_frame (lafan1/utils.py:111-137) about
+ * their first frame's head heading, joint positions min/max-normalised (amass_diffusion_dataset.py:379-392), rotations
+ * as 6D.  d_aa [B][Tw][22][3], d_root [B][Tw][3] (egoego_convert_model_res' outputs, root already shifted),
+ * d_rest_offsets [22][3] = ds.rest_human_offsets, parents_host[22] as above -> d_prefix [B][n_last][198], the
+ * `d_prefix` argument of egoego_sample_loop for the next window. */
+int egoego_window_prefix(const float* d_aa, const float* d_root, const float* d_rest_offsets, const float* d_jpos_min,
+                         const float* d_jpos_max, const int32_t* parents_host, int head_idx, int B, int Tw, int n_last,
+                         float* d_prefix, void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
  * kernel_id: EGOEGO_K_*.  begin() arms event pairs around every launch of that kernel;
  * end() synchronises the stream's events and returns the mean duration and launch count. */

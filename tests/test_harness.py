@@ -139,3 +139,53 @@ def test_convert_model_res_hip_kernel_vs_torch_chain():
     assert (R.axis_angle_to_matrix(got[0].cpu()) - R.axis_angle_to_matrix(want[0])).abs().max().item() < 1e-5
     with pytest.raises(Exception, match="earlier joint"):
         harness.convert_model_res_to_data(ds, x.cuda(), rec.cuda(), parents=(-1,) + (5,) * 21)
+
+
+@pytest.mark.gpu
+def test_window_prefix_hip_kernel_vs_torch_chain():
+    """egoego_window_prefix (fk_smpl + rotate_at_frame + normalisation + 6D in one HIP kernel, M:399-467) against the torch
+    chain the harness runs for CPU tensors."""
+    g = torch.Generator().manual_seed(77)
+    B, Tw, n_last = 3, 23, 10
+    aa = torch.randn(B, Tw, 22, 3, generator=g) * 0.7
+    aa[0, :, 5] = 0.0            # zero rotation: the small-angle branch
+    root = torch.randn(B, Tw, 3, generator=g)
+    lo, hi = -torch.rand(66, generator=g) - 1.5, torch.rand(66, generator=g) + 1.5
+    ds = harness.SkeletonStats(lo, hi, torch.randn(22, 3, generator=g) * 0.2)
+    got = harness._window_prefix_hip(ds, aa.cuda(), root.cuda(), n_last)
+    assert got is not None and got.shape == (B, n_last, 198)
+    # the torch chain, as written in p_sample_loop_sliding_window_w_canonical
+    gq, gj = ds.fk_smpl(root.reshape(-1, 3), aa.reshape(-1, 22, 3))
+    gq = gq.reshape(B, -1, 22, 4)[:, -n_last:]
+    gj = gj.reshape(B, -1, 22, 3)[:, -n_last:]
+    t_trans, _, t_rec = harness.rotate_at_frame(gj[:, :, harness.HEAD_IDX, :], gq[:, :, harness.HEAD_IDX, :], 0)
+    t_move = t_trans[:, 0:1, :].clone()
+    t_move[:, :, 2] = 0
+    inv = R.quaternion_invert(t_rec.float()).expand(B, n_last, 22, 4)
+    pj = R.quaternion_apply(inv, gj) - t_move[:, :, None, :]
+    pj = ds.normalize_jpos_min_max(pj.reshape(-1, 22, 3)).reshape(B, -1, 66)
+    p6 = R.matrix_to_rotation_6d(R.quaternion_to_matrix(R.quaternion_multiply(inv, gq))).reshape(B, -1, 132)
+    want = torch.cat((pj, p6), dim=-1)
+    assert (got.cpu() - want).abs().max().item() < 2e-5
+    assert harness._window_prefix_hip(ds, aa, root, n_last) is None  # CPU tensors: the torch chain is used
+
+
+@pytest.mark.gpu
+def test_window_condition_hip_kernel_vs_torch_chain():
+    """egoego_window_condition against the torch expressions of the harness (rotate_at_frame etc., M:355-378)."""
+    g = torch.Generator().manual_seed(12)
+    B, Tw = 4, 57
+    jpos = torch.randn(B, Tw, 3, generator=g)
+    jquat = torch.nn.functional.normalize(torch.randn(B, Tw, 4, generator=g), dim=-1)
+    lo, hi = -torch.rand(66, generator=g) - 1.5, torch.rand(66, generator=g) + 1.5
+    ds = harness.SkeletonStats(lo, hi, torch.zeros(22, 3))
+    x_start, rec = harness._window_condition_hip(ds, jpos.cuda(), jquat.cuda())
+    al_trans, al_quat, recover = harness.rotate_at_frame(jpos, jquat, 0)
+    move0 = al_trans[:, 0:1, :].clone()
+    move0[:, :, 2] = 0
+    want = torch.zeros(B, Tw, 198)
+    want[:, :, 45:48] = al_trans - move0
+    want[:, :, 66 + 90:66 + 96] = R.matrix_to_rotation_6d(R.quaternion_to_matrix(al_quat))
+    want[:, :, :66] = ds.normalize_jpos_min_max(want[:, :, :66].reshape(-1, 22, 3)).reshape(B, -1, 66)
+    assert (x_start.cpu() - want).abs().max().item() < 1e-5
+    assert (rec.cpu() - recover).abs().max().item() < 1e-6 and rec.shape == recover.shape
