@@ -96,9 +96,7 @@ def test_p_sample_golden(golden, objective, prec):
         x_in = x.cuda()
         y = m.p_sample(x_in, torch.full((2,), tval).cuda(), xc.cuda(), noise=noise.cuda())
         assert torch.equal(x_in.cpu(), x)  # like the reference, p_sample returns a new tensor
-        # pred_noise divides by sqrt(abar): errors are amplified by sqrt_recipm1 (~3.4 at t=500)
-        tol = POSE_TOL if objective == "pred_x0" else 5 * POSE_TOL
-        assert np.abs(y.cpu().numpy() - golden[f"p_sample_{objective}_t{tval}"]).max() < tol, (objective, tval)
+        assert np.abs(y.cpu().numpy() - golden[f"p_sample_{objective}_t{tval}"]).max() < POSE_TOL, (objective, tval)
 
 
 def test_p_sample_default_noise_uses_torch_generator():

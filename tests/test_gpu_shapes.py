@@ -1,0 +1,192 @@
+"""GPU parity at the BASELINE.json sizes the small-batch tests do not reach:
+
+  * configs[2]  B=256 x T=120: 20 ancestral steps with injected noise, oracle on the first / last window of a
+    128-row chunk and of the grid (windows 0, 127, 128, 255);
+  * configs[1]  B=64 x T=120 and the 2-GPU shard size B=128: the mid-batch dispatch (separate fc+LN / FFN kernels on
+    64-token tiles), oracle on three windows + bit-invariance against the same windows inside a B=256 batch;
+  * configs[3]  B=256 x T=196: denoiser + ancestral steps against the oracle on two windows, and the 50-step DDIM
+    sampler at full size (oracle restatement on two windows; no reference DDIM exists);
+  * the int8-slice kernel's real window range (T+1 = 65 .. 128) at its boundaries.
+
+The oracle (bit-identical to the reference, tests/golden/make_golden.py) only ever runs on the few windows compared:
+windows are independent for the whole chain, so a window's result inside a large batch must equal the oracle's result
+for that window alone.
+"""
+import numpy as np
+import pytest
+import torch
+
+from egoego_release_amd import ModelConfig, make_weights, make_head_windows, _lib
+from egoego_release_amd.model import CondGaussianDiffusion
+from oracle import egoego_oracle as O
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-3  # BASELINE.json north_star: <= 1e-3 max-abs on the pose tensor
+
+
+@pytest.fixture(params=[_lib.PREC_BF16X3, _lib.PREC_I8X3], ids=["bf16x3", "i8x3"])
+def prec(request):
+    return request.param
+
+
+def _model(T=120, objective="pred_x0", precision=3):
+    cfg = ModelConfig(max_timesteps=T + 1, objective=objective)
+    sd = make_weights(cfg, 0)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m.hip_precision = precision
+    return cfg, sd, m.cuda()
+
+
+def _inputs(B, T, seed):
+    """x_T, x_cond on the GPU (generated there: the full-size noise would be ~0.5 GB of CPU randn)."""
+    xs, cm = make_head_windows(B, T, seed=seed)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(xs.shape, generator=g, device="cuda")
+    xc = (xs.cuda() * (1 - cm.cuda()) + cm.cuda() * torch.randn(xs.shape, generator=g, device="cuda")).contiguous()
+    return x, xc, g
+
+
+def _oracle_chain(sd, x, xc, steps_noise, t_start, objective="pred_x0"):
+    sched = O.make_schedule(1000)
+    b = x.shape[0]
+    for i in range(steps_noise.shape[0]):
+        x = O.p_sample(sd, sched, x, torch.full((b,), t_start - i), xc, steps_noise[i], objective)
+    return x
+
+
+@pytest.mark.parametrize("t_start", [999, 19])
+def test_b256_t120_twenty_steps_against_oracle(prec, t_start):
+    """'B=256 for <= 20 steps'.  t_start=19 ends on t=0, i.e. on the chain's final clamp(x0)."""
+    cfg, sd, m = _model(precision=prec)
+    eng = m.hip_engine()
+    B, T, S = 256, 120, 20
+    x, xc, g = _inputs(B, T, 31)
+    noise = torch.randn(S, B, T, 198, generator=g, device="cuda")
+    pick = [0, 127, 128, 255]
+    x0_cpu, xc_cpu, nz_cpu = x[pick].cpu(), xc[pick].cpu(), noise[:, pick].cpu()
+    eng.sample_loop_(x, xc, t_start, S, noise=noise)
+    with torch.no_grad():
+        want = _oracle_chain(sd, x0_cpu, xc_cpu, nz_cpu, t_start)
+    err = (x[pick].cpu() - want).abs().max().item()
+    assert err < POSE_TOL, err
+    assert torch.isfinite(x).all()
+    if t_start == 19:
+        assert x.abs().max().item() <= 1.0
+
+
+@pytest.mark.parametrize("B", [64, 128, 192])
+def test_mid_batch_dispatch_against_oracle_and_b256(prec, B):
+    """B=64 is configs[1]'s batch, 128 the per-rank shard of the 2-GPU split of configs[2]; 192 sits just below the
+    switch to the fused layer tail.  Three windows against the oracle, and all of them bit-equal to the same windows
+    run inside a B=256 batch (every kernel accumulates an output element in the same order whatever its tiling)."""
+    cfg, sd, m = _model(precision=prec)
+    eng = m.hip_engine()
+    T, S = 120, 4
+    x, xc, g = _inputs(256, T, 47)
+    noise = torch.randn(S, 256, T, 198, generator=g, device="cuda")
+    t = torch.randint(0, 1000, (256,), generator=torch.Generator().manual_seed(3)).cuda()
+    big = m.denoise(x, t, xc)
+    small = m.denoise(x[:B].contiguous(), t[:B].contiguous(), xc[:B].contiguous())
+    assert (big[:B] - small).abs().max().item() <= 1e-6
+    pick = [0, B // 2, B - 1]
+    with torch.no_grad():
+        want = O.denoise(sd, torch.cat((x[pick].cpu(), xc[pick].cpu()), -1), t[pick].cpu())
+    assert (small[pick].cpu() - want).abs().max().item() < POSE_TOL
+    a, b = x.clone(), x[:B].contiguous().clone()
+    eng.sample_loop_(a, xc, 700, S, noise=noise)
+    eng.sample_loop_(b, xc[:B].contiguous(), 700, S, noise=noise[:, :B].contiguous())
+    assert (a[:B] - b).abs().max().item() <= 1e-6
+    with torch.no_grad():
+        want = _oracle_chain(sd, x[pick].cpu(), xc[pick].cpu(), noise[:, pick].cpu(), 700)
+    assert (b[pick].cpu() - want).abs().max().item() < POSE_TOL
+
+
+def test_b256_t196_against_oracle(prec):
+    """BASELINE configs[3] shape: denoiser forward and 6 ancestral steps at B=256, T=196 (L=197, 7 key tiles)."""
+    T, B, S = 196, 256, 6
+    cfg, sd, m = _model(T, precision=prec)
+    eng = m.hip_engine()
+    x, xc, g = _inputs(B, T, 59)
+    pick = [0, 255]
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(5)).cuda()
+    y = m.denoise(x, t, xc)
+    with torch.no_grad():
+        want = O.denoise(sd, torch.cat((x[pick].cpu(), xc[pick].cpu()), -1), t[pick].cpu())
+    assert (y[pick].cpu() - want).abs().max().item() < POSE_TOL
+    noise = torch.randn(S, B, T, 198, generator=g, device="cuda")
+    x0_cpu = x[pick].cpu()
+    eng.sample_loop_(x, xc, 5, S, noise=noise)
+    with torch.no_grad():
+        want = _oracle_chain(sd, x0_cpu, xc[pick].cpu(), noise[:, pick].cpu(), 5)
+    assert (x[pick].cpu() - want).abs().max().item() < POSE_TOL
+    assert torch.isfinite(x).all() and x.abs().max().item() <= 1.0
+    # batch invariance at this length too
+    z = m.denoise(x[:2].contiguous(), t[:2].contiguous(), xc[:2].contiguous())
+    zz = m.denoise(x, t, xc)
+    assert (zz[:2] - z).abs().max().item() <= 1e-6
+
+
+def test_b256_t196_ddim_50_steps(prec):
+    """configs[3]'s sampler at its real size: 50-step DDIM over B=256 windows of 196 frames.  No reference DDIM
+    exists: two windows are checked against the oracle's restatement of the published update."""
+    T, B = 196, 256
+    cfg, sd, m = _model(T, precision=prec)
+    xs, cm = make_head_windows(B, T, seed=13)
+    g = torch.Generator().manual_seed(17)
+    pick = [3, 250]
+    nz = {"x_T": torch.randn(xs.shape, generator=g), "cond": torch.randn(xs.shape, generator=g)}
+    y = m.ddim_sample(xs.cuda(), cm.cuda(), n_steps=50, noise=nz)
+    assert torch.isfinite(y).all() and y.abs().max().item() <= 1.0 + 1e-6
+    ts = sorted({int(round(v)) for v in np.linspace(0, 999, 50)}, reverse=True)
+    xc = xs[pick] * (1 - cm[pick]) + cm[pick] * nz["cond"][pick]
+    with torch.no_grad():
+        want = O.ddim_loop(sd, O.make_schedule(1000), nz["x_T"][pick].clone(), xc, ts)
+    assert (y[pick].cpu() - want).abs().max().item() < POSE_TOL
+    # deterministic sampler: a second run is bit-identical
+    y2 = m.ddim_sample(xs.cuda(), cm.cuda(), n_steps=50, noise=nz)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("B,T", [(3, 64), (2, 65), (5, 100), (64, 64)])
+def test_int8_window_range_boundaries(prec, B, T):
+    """The int8-slice attention-layer kernel serves every window of 65..128 tokens (four key tiles): its lower
+    boundary T=64 (L=65), T=65, and a mid length with many padded keys, at small and one-wave batch sizes."""
+    cfg = ModelConfig(max_timesteps=T + 1)
+    sd = make_weights(cfg, 1)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m.hip_precision = prec
+    m = m.cuda()
+    g = torch.Generator().manual_seed(10 * T + B)
+    x_all = torch.randn(B, T, 396, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    pick = sorted({0, B // 2, B - 1})
+    with torch.no_grad():
+        want = O.denoise(sd, x_all[pick], t[pick])
+    got = m.denoise(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda()).cpu()
+    assert (got[pick] - want).abs().max().item() < POSE_TOL
+
+
+def test_pred_noise_objective_all_timesteps(prec):
+    """Row A7 (M:216-220): x0 = sqrt(1/abar) x - sqrt(1/abar - 1) out, clamp to [-1, 1], posterior.  An output error e
+    reaches the step result as coef1[t] * sqrt(1/abar_t - 1) * e — an amplification below 0.3 for t <= 980, where the
+    result must meet the same 1e-3 bar as pred_x0.  In the last few timesteps the map itself is ill-conditioned
+    (sqrt(1/abar - 1) = 2e4 at t=999: fp32 rounding of the REFERENCE's own x0 is already O(1) before the clamp); there
+    the clamp bounds the deviation by 2 * coef1[t] = 3e-3, which is what is asserted."""
+    cfg, sd, m = _model(objective="pred_noise", precision=prec)
+    sched = O.make_schedule(1000)
+    amp = sched["posterior_mean_coef1"] * sched["sqrt_recipm1_alphas_cumprod"]
+    assert amp[:981].max().item() < 0.3
+    g = torch.Generator().manual_seed(2024)
+    x = torch.randn(2, 120, 198, generator=g) * 0.5
+    xc = torch.randn(2, 120, 198, generator=g)
+    noise = torch.randn(x.shape, generator=g)
+    for tval in (0, 1, 100, 500, 900, 980, 999):
+        t = torch.full((2,), tval)
+        with torch.no_grad():
+            want = O.p_sample(sd, sched, x, t, xc, noise, "pred_noise")
+        got = m.p_sample(x.cuda(), t.cuda(), xc.cuda(), noise=noise.cuda()).cpu()
+        err = (got - want).abs().max().item()
+        bound = POSE_TOL if tval <= 980 else 2 * sched["posterior_mean_coef1"][tval].item() + 1e-4
+        assert err < bound, (tval, err)
