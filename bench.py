@@ -6,10 +6,10 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one p_sample (denoiser forward + DDPM posterior update, in-kernel Philox noise) applied to
-a batch of B=256 windows of T=120 frames x 198 features with inputs resident in HBM.  With N GPUs every
-rank samples its own B windows (independent windows shard with no data-path collective; weak scaling)
-and one RCCL all_gather of the final poses to every rank closes the timed region.  Rank 0 prints ONE
-JSON line.
+the GLOBAL batch of B=256 windows of T=120 frames x 198 features with inputs resident in HBM.  With N GPUs
+the batch is split (egoego_release_amd.dist: contiguous window shards, no data-path collective; STRONG
+scaling) and one RCCL all_gather of the poses to every rank closes the timed region.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -90,12 +90,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="GLOBAL number of windows (split over the GPUs)")
     ap.add_argument("--window", type=int, default=120)
     ap.add_argument("--precision", type=int, default=8, choices=(1, 3, 8),
-                    help="8 = i8x3 attention kernel + split-bf16 elsewhere (parity-grade, default), 3 = split-bf16 everywhere "
-                         "(parity-grade), 1 = plain bf16 (NOT parity-grade)")
+                    help="8 = int8-slice attention layer + split-bf16 elsewhere (parity-grade, default), 3 = split-bf16 "
+                         "everywhere (parity-grade), 1 = plain bf16 (NOT parity-grade)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step (no hipGraph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", default=None, help="rank 0 saves the gathered poses of the timed call here (tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +126,7 @@ def main():
     from egoego_release_amd import ModelConfig, make_weights, make_head_windows
     from egoego_release_amd.model import CondGaussianDiffusion
     from egoego_release_amd import _lib
+    from egoego_release_amd import dist as D
 
     B, T = args.batch, args.window
     cfg = ModelConfig(max_timesteps=T + 1)
@@ -131,111 +134,121 @@ def main():
     model = CondGaussianDiffusion(**cfg.ctor_kwargs())
     model.load_state_dict(sd, strict=False)
     model.hip_precision = args.precision
+    model.hip_graph = not args.no_graph
     model = model.to(dev)
     eng = model.hip_engine()
 
-    xs, cm = make_head_windows(B, T, seed=100 + rank)
-    gen = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(xs.shape, generator=gen).to(dev)
-    x_cond = (xs * (1 - cm) + cm * torch.randn(xs.shape, generator=gen)).to(dev)
+    # the GLOBAL batch (every rank holds it: 24 MB per tensor at B=256); rank r samples the contiguous slice
+    # dist.shard_bounds gives it (strong scaling: BASELINE configs[2] is B=256 split over the GPUs of the node)
+    xs, cm = make_head_windows(B, T, seed=100)
+    gen = torch.Generator().manual_seed(1234)
+    noise = {"x_T": torch.randn(xs.shape, generator=gen).to(dev), "cond": torch.randn(xs.shape, generator=gen).to(dev)}
+    xs, cm = xs.to(dev), cm.to(dev)
+    lo, hi = D.shard_bounds(B, rank, world)
     S = cfg.timesteps
     K, W = args.steps, args.warmup
+    if K + W > S:
+        raise SystemExit(f"steps + warmup must not exceed the {S}-step chain")
 
-    def run_steps(n, t_hi):
-        done = 0
-        while done < n:  # wrap around the 1000-step chain if asked for more steps than it has
-            t_start = (t_hi - done) % S
-            m = min(n - done, t_start + 1)
-            eng.sample_loop_(x, x_cond, t_start, m, noise_mode=_lib.NOISE_PHILOX, seed=7, window_offset=rank * B)
-            done += m
-
-    run_steps(W, S - 1)
-    gathered = [torch.empty_like(x) for _ in range(world)] if world > 1 else None
+    # warm-up: W untimed steps through the very path that is timed (packs the workspace, captures the step graph)
+    if W:
+        D.sample_sharded(D.hip_steps_fn(model, S - 1, W, seed=7), xs, cm, noise)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.profile_begin("qkv")  # HIP events around every launch of the attention-layer kernel inside the timed region
     t0 = time.perf_counter()
-    run_steps(K, S - 1 - W)
-    if dist:
-        dist.all_gather(gathered, x)  # the one collective of the path: final poses over xGMI
+    # K steps of this rank's shard (no collective in the loop), then the ONE all_gather of the path
+    out = D.sample_sharded(D.hip_steps_fn(model, S - 1 - W, K, seed=7), xs, cm, noise)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    k_us, k_n = eng.profile_end()
     if dist:
         tmax = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = tmax.item()
-    finite = bool(torch.isfinite(x).all().item())
+    finite = bool(torch.isfinite(out).all().item()) and tuple(out.shape) == (B, T, cfg.d_feats)
+    if args.dump and rank == 0:
+        torch.save(out.cpu(), args.dump)
 
-    # the other heavy kernel (layer tail), timed the same way over a few extra untimed steps
-    eng.profile_begin("fc_ln")
-    run_steps(min(K, 10), S - 1 - W - K)
-    torch.cuda.synchronize()
-    t_us, t_n = eng.profile_end()
+    # per-kernel launch durations (HIP events on the launch stream), measured AFTER the timed region on this rank's
+    # shard: a few extra steps per kernel with event pairs around every launch of that kernel
+    Bl = hi - lo
+    x_l = noise["x_T"][lo:hi].contiguous().clone()
+    xc_l = (xs[lo:hi] * (1 - cm[lo:hi]) + cm[lo:hi] * noise["cond"][lo:hi]).contiguous()
+    kern = {}
+    for name in ("qkv", "fc_ln"):
+        eng.profile_begin(name)
+        eng.sample_loop_(x_l, xc_l, S - 1 - W, min(K, 20), noise_mode=_lib.NOISE_PHILOX, seed=7, window_offset=lo)
+        torch.cuda.synchronize()
+        kern[name] = eng.profile_end()
+    (k_us, k_n), (t_us, t_n) = kern["qkv"], kern["fc_ln"]
 
-    traffic = {}
-    try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (profiles/)
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+    traffic, traffic_src = {}, None
+    try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command, summarised under profiles/
+        tp = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        with open(tp) as f:
             tj = json.load(f)
-        if (B, T, args.precision) == (tj.get("batch"), tj.get("window"), tj.get("precision")):
+        if (Bl, T, args.precision) == (tj.get("batch"), tj.get("window"), tj.get("precision")):
             traffic = tj["kernels"]
+            traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)"
     except Exception:
         traffic = {}
 
     if rank == 0:
-        steps_per_s = world * K / el
+        steps_per_s = K / el
         fl_step = flops_per_window_step(T) * B
-        i8 = args.precision == 8 and 96 < T + 1 <= 128
+        i8 = args.precision == 8 and 64 < T + 1 <= 128
         attn_name = "attn_layer_i8_kernel" if i8 else "qkv_attn_kernel"
         attn_peak = PEAK_I8_TOPS if i8 else PEAK_BF16_TFLOPS
-        attn_ach = qkv_attn_flops_per_launch(B, T) / (k_us * 1e-6) / 1e12 if k_n else None
-        tail_ach = tail_flops_per_launch(B, T) / (t_us * 1e-6) / 1e12 if t_n else None
+        attn_ach = qkv_attn_flops_per_launch(Bl, T) / (k_us * 1e-6) / 1e12 if k_n else None
+        tail_ach = tail_flops_per_launch(Bl, T) / (t_us * 1e-6) / 1e12 if t_n else None
         L = T + 1
+        ms_step = 1e3 * el / K
         attn_roof = {
             "bound": "mfma", "kernel": attn_name + (" (Q/K/V projections, softmax and PV of one window x head per workgroup, int8 slices; "
                                                     "K, V and the probabilities stay in LDS/registers)" if i8 else
                                                     " (fused Q/K/V projection + attention, split-bf16)"),
             "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if i8 else "TFLOP/s",
             "frac": (attn_ach / attn_peak) if attn_ach else None,
-            "traffic": (traffic.get(attn_name) or {}).get("hbm_bytes_per_launch"),
-            "algorithmic_bytes": (2 * B * L * 512 + 4 * B * L * 1024 + 3 * 2 * 512 * 1024) if i8 else (4 * B * L * (512 + 1024) + 6.3e6),
-            "launch_us": k_us, "launches": k_n, "share_of_step": 4 * k_us / (1e3 * el / K) / 1e3 if k_n else None,
-            "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time measured inside the timed region; three "
-                    "MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe utilisation is 3x this fraction. "
-                    "Under MFMA load the chip sustains ~2.0 GHz, i.e. ~4.1 POP/s int8 / ~1.9 PFLOP/s bf16 (tools/microbench/mfma_rate.hip); DESIGN.md section 6 has the breakdown."}
+            "traffic": (traffic.get(attn_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
+            "algorithmic_bytes": (2 * Bl * L * 512 + 4 * Bl * L * 1024 + 3 * 2 * 512 * 1024) if i8 else (4 * Bl * L * (512 + 1024) + 6.3e6),
+            "launch_us": k_us, "launches": k_n, "share_of_step": 4 * k_us / (1e3 * ms_step) if k_n else None,
+            "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time, measured on rank 0's shard right after "
+                    "the timed region; three MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe "
+                    "utilisation is 3x this fraction"}
         tail_roof = {
-            "bound": "mfma", "kernel": "layer_tail_kernel (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 128 tokens, split-bf16)",
+            "bound": "mfma", "kernel": "layer_tail_kernel (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, split-bf16)",
             "achieved": tail_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (tail_ach / PEAK_BF16_TFLOPS) if tail_ach else None,
-            "traffic": (traffic.get("layer_tail_kernel") or {}).get("hbm_bytes_per_launch"),
-            "algorithmic_bytes": 4 * B * L * (1024 + 512 + 512) + 4.2e6,
-            "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * el / K) / 1e3 if t_n else None,
-            "note": "timed over extra steps right after the timed region; split-bf16 issues 3 MFMAs per product (pipe utilisation 3x)"}
+            "traffic": (traffic.get("layer_tail_kernel") or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
+            "algorithmic_bytes": 4 * Bl * L * (1024 + 512 + 512) + 4.2e6,
+            "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * ms_step) if t_n else None,
+            "note": "measured like the attention-layer kernel; split-bf16 issues 3 MFMAs per product (pipe utilisation 3x)"}
         dominant, other = (attn_roof, tail_roof) if (k_us or 0) >= (t_us or 0) else (tail_roof, attn_roof)
-        out = {
-            "metric": "diffusion-steps/sec (B=256, T=120, 22-joint)",
+        out_json = {
+            "metric": f"diffusion-steps/sec (B={B}, T={T}, 22-joint)",
             "value": steps_per_s,
             "unit": "diffusion-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": 1e3 * el / K,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": {8: "i8x3 + bf16x3 (attention layer: 2 x int8 slices per operand, int32 accumulate; rest: split-bf16, fp32 accumulate)",
                       3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)", 1: "bf16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: B={B} windows/GPU x T={T} frames x 198 feats, 1000-step DDPM chain "
-                                   f"(steps {S - 1 - W}..{S - W - K} timed), in-kernel Philox noise, synthetic seeded weights",
-                       "windows_per_gpu": B, "window_len": T, "global_windows": B * world,
-                       "parallelism": f"window-sharded x{world}, one all_gather at the end"},
+            "config": {"workload": f"BASELINE configs[2]: B={B} windows x T={T} frames x 198 feats split over {world} GPU(s) "
+                                   f"({Bl} windows on rank 0), 1000-step DDPM chain (steps {S - 1 - W}..{S - W - K} timed), in-kernel "
+                                   f"Philox noise keyed by the global window index, synthetic seeded weights",
+                       "global_windows": B, "windows_per_gpu": Bl, "window_len": T,
+                       "parallelism": f"window-sharded x{world} (dist.sample_sharded), one all_gather of the poses inside the timed region",
+                       "hip_graph": not args.no_graph},
             "window_steps_per_s": steps_per_s * B,
-            "step_tflops_algorithmic": fl_step * steps_per_s / world / 1e12,
+            "step_tflops_algorithmic": fl_step * steps_per_s / 1e12,
             "step_frac_of_bf16_peak": fl_step * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS,
             "output_finite": finite,
             "roofline": dominant,
@@ -243,11 +256,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, sd, B, T)
-                out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
+                out_json["cpu_baseline"] = cpu_baseline(cfg, sd, B, T)
+                out_json["speedup_vs_cpu_baseline"] = steps_per_s / out_json["cpu_baseline"]["value"]
             except Exception as e:  # the GPU number stands on its own
-                out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+                out_json["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out_json), flush=True)
     if dist:
         dist.destroy_process_group()
 

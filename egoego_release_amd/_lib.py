@@ -6,9 +6,11 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("EGOEGO_HIP_LIB") or os.path.join(_PKG, "libegoego_hip.so")  # override: perf-debug builds only
+LIB_PATH = os.path.join(_PKG, "libegoego_hip.so")
+PERFDEBUG_LIB_PATH = os.path.join(_PKG, "libegoego_hip_perfdebug.so")  # tools/ only: `build --perfdebug`
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+FLAG_NO_GRAPH = 1
 PRED_NOISE, PRED_X0 = 0, 1
 NOISE_INJECTED, NOISE_PHILOX, NOISE_NONE = 0, 1, 2
 PREC_BF16X3, PREC_BF16X1, PREC_I8X3 = 3, 1, 8
@@ -22,7 +24,7 @@ c_float_p = C.POINTER(C.c_float)
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d_feats", "d_model", "n_head", "n_dec_layers", "d_k", "d_v",
-                                          "max_timesteps", "num_timesteps", "objective", "precision")]
+                                          "max_timesteps", "num_timesteps", "objective", "precision", "flags")]
 
 
 class LayerWeights(C.Structure):
@@ -52,6 +54,15 @@ _lib = None
 
 class EgoEgoHipError(RuntimeError):
     pass
+
+
+def use_perfdebug_build():
+    """tools/*_trace.py only: bind the perf-debug build (per-block timestamps, stage ablation) instead of the product
+    library.  Must be called before the first load()."""
+    global LIB_PATH
+    if _lib is not None:
+        raise EgoEgoHipError("use_perfdebug_build() must be called before the library is loaded")
+    LIB_PATH = PERFDEBUG_LIB_PATH
 
 
 def load():

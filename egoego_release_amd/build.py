@@ -25,17 +25,25 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/*.hip -> egoego_release_amd/libegoego_hip.so (gfx950 only)."""
-    if not force and not is_stale():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB]
+def build(force=False, verbose=False, perfdebug=False, defines=()):
+    """Compile csrc/*.hip -> egoego_release_amd/libegoego_hip.so (gfx950 only).
+
+    perfdebug=True builds libegoego_hip_perfdebug.so instead: the same sources with -DEGOEGO_PERFDEBUG (per-block
+    timestamps, stage ablation; plus any extra `defines` such as EGOEGO_ABLATE_MAINLOOP=1) for tools/*_trace.py.
+    The product library contains none of that."""
+    out = LIB.replace(".so", "_perfdebug.so") if perfdebug else LIB
+    if not force and not perfdebug and not is_stale():
+        return out
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out]
+    if perfdebug:
+        cmd += ["-DEGOEGO_PERFDEBUG"] + [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, perfdebug="--perfdebug" in sys.argv,
+                defines=[a[2:] for a in sys.argv if a.startswith("-D")]))

@@ -32,8 +32,8 @@ struct AttnLayerArgs {
     size_t o_plane;
     int HD16;
     float qscale;
-    int H, L, bh0, ablate;
-    unsigned long long* trace;  // perf-debug: [grid][16] phase timestamps or nullptr
+    int H, L, bh0;
+    EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][16] phase timestamps or nullptr
 };
 
 using AL8K = GemmCfg<4, 2, 2, 2, 1, 2, false, 1, 3>;
@@ -62,13 +62,14 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
     // operand strides are counted in bf16 elements (2 bytes) by the main loop; K16 counts 32-wide k blocks here
-    const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0, 0, nullptr};
-    unsigned long long* tr = a.trace ? a.trace + 131072 + (size_t)blockIdx.x * 16 : nullptr;
+    const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
+    EG_DBG(unsigned long long* tr = a.trace ? a.trace + 131072 + (size_t)blockIdx.x * 16 : nullptr;)
     auto mark = [&](int i) {
-        if (tr && threadIdx.x == 0) {
+        EG_DBG(if (tr && threadIdx.x == 0) {
             tr[i] = wall_clock64();
             if (i < 2) tr[12 + i] = __builtin_readcyclecounter();
-        }
+        })
+        (void)i;
     };
     mark(0);
     {
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
             }
         }
     }
-    if (tr) {
+    EG_DBG(if (tr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mark(8);
-    }
+    })
 }

@@ -45,6 +45,26 @@ struct LayerDev {
     float *b_qkv, *b_fc, *ln1_g, *ln1_b, *b_1, *b_2, *ln2_g, *ln2_b;
 };
 
+// One captured diffusion step (k_step_begin + embed + layers + out).  Everything a kernel of the step receives by
+// value is part of the key; what changes from step to step (t, the step index that selects the injected-noise
+// slice or the DDIM table row) lives in device memory (Workspace::state), so ONE graph serves every step of a chain.
+struct StepKey {
+    int B, T, mode, noise_mode, prefix_len, clip, ddim;
+    const void *x, *noise, *prefix, *ws;
+    uint64_t seed;
+    int64_t window_offset;
+    bool operator==(const StepKey& o) const {
+        return B == o.B && T == o.T && mode == o.mode && noise_mode == o.noise_mode && prefix_len == o.prefix_len && clip == o.clip &&
+               ddim == o.ddim && x == o.x && noise == o.noise && prefix == o.prefix && ws == o.ws && seed == o.seed &&
+               window_offset == o.window_offset;
+    }
+};
+struct StepGraph {
+    StepKey key;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
 struct egoego_ctx {
     egoego_config cfg;
     int device;
@@ -55,17 +75,22 @@ struct egoego_ctx {
     std::vector<LayerDev> layers;
     bool have_weights, have_sched;
     std::vector<float> abar_host;
+    // hipGraph replay of the per-step launch sequence (egoego_sample_loop / egoego_ddim_loop)
+    hipStream_t cap_stream;
+    std::vector<StepGraph> graphs;
+    std::vector<int> ddim_ts_host;
+    std::vector<float> ddim_abar_host;
     // profiling
     int prof_id;
     std::vector<hipEvent_t> prof_events;
 };
 
 static const int N_MODEL = 512;
-static unsigned long long* g_trace = nullptr;  // perf-debug: set by egoego_debug_trace_buffer
-static int g_chunk = getenv("EGOEGO_CHUNK") ? atoi(getenv("EGOEGO_CHUNK")) : 0;  // windows per denoiser pass (0 = whole batch)
-static int g_fuse_attn = getenv("EGOEGO_FUSE_ATTN") ? atoi(getenv("EGOEGO_FUSE_ATTN")) : 1;  // 0: separate qkv + attention kernels
-static int g_fuse_tail = getenv("EGOEGO_FUSE_TAIL") ? atoi(getenv("EGOEGO_FUSE_TAIL")) : 1;  // 0: separate fc_ln / ffn1 / ffn2_ln kernels
-static int g_ablate = getenv("EGOEGO_ABLATE") ? atoi(getenv("EGOEGO_ABLATE")) : 0;  // perf-debug only
+#ifdef EGOEGO_PERFDEBUG
+// perf-debug build only (tools/*_trace.py): per-block timestamps and stage ablation, set through egoego_debug_*
+static unsigned long long* g_trace = nullptr;
+static int g_ablate = 0;
+#endif
 
 struct Geometry {
     int B, T, L, KT, Lp, Mp, Mvalid;
@@ -89,6 +114,9 @@ static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g) {
 }
 
 struct Workspace {
+    int* state;       // [4]: {steps begun, t of the first step} — device-resident so a captured step replays for any t
+    int* step_ts;     // [S] explicit timestep list (DDIM)
+    float* step_abar; // [S] alphas_cumprod of the NEXT list entry (DDIM)
     int* t_idx;
     float* row_mask;
     __bf16 *xall, *hA, *hB, *F, *Q, *K, *V, *O;
@@ -105,6 +133,9 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
         off += align_up(bytes, 256);
         return p;
     };
+    w.state = (int*)take(sizeof(int) * 4);
+    w.step_ts = (int*)take(sizeof(int) * c->S);
+    w.step_abar = (float*)take(sizeof(float) * c->S);
     w.t_idx = (int*)take(sizeof(int) * g.B);
     w.row_mask = (float*)take(sizeof(float) * g.Mp);
     w.xall_plane = (size_t)g.Mp * c->KE;
@@ -137,12 +168,12 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperan
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the H heads of a window share an XCD (and its L2)
     const int bh = lid + a.bh0;
     const int b = bh / H, h = bh - b * H;
-    unsigned long long* tr = g.trace ? g.trace + 131072 + (size_t)blockIdx.x * 8 : nullptr;  // perf-debug marks
-    if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
+    EG_DBG(unsigned long long* tr = g.trace ? g.trace + 131072 + (size_t)blockIdx.x * 8 : nullptr;
+           if (tr && threadIdx.x == 0) tr[0] = wall_clock64();)
     GemmBody<CQK, EQK>::run(g, eqk, H + h, b, smem);     // K_h -> global (accumulator order along d_k)
-    if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
+    EG_DBG(if (tr && threadIdx.x == 0) tr[1] = wall_clock64();)
     GemmBody<CV, EV>::run(g, ev, 2 * H + h, b, smem);    // V_h -> global (transposed, key-permuted)
-    if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
+    EG_DBG(if (tr && threadIdx.x == 0) tr[2] = wall_clock64();)
     // Q_h last, with waves laid out 1(f) x 4(t): wave w ends up holding all 256 d_k of its 32 queries.
     // It never goes to memory: bias, 1/sqrt(d_k), split-bf16 — and the accumulator registers 8jj..8jj+7 of
     // feature tile i ARE the B-operand fragment of k-step 2i+jj in the order K was stored in.
@@ -172,12 +203,13 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperan
     // this workgroup's own K/V stores must have reached L2 before its LDS-DMAs of them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
-    if (!(g.ablate & 4)) attn_body<KT, NP, true>(a, bh, 0, smem, qh, ql);  // ablate bit 2: skip attention (perf-debug)
-    if (tr) {
+    EG_DBG(if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
+           if (g.ablate & 4) return;)
+    attn_body<KT, NP, true>(a, bh, 0, smem, qh, ql);
+    EG_DBG(if (tr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) tr[4] = wall_clock64();
-    }
+    })
 }
 
 // ------------------------------------------------------------------------------------ fused layer tail
@@ -311,16 +343,16 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     // i8x3: windows of 97..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
     // layer reads the embed output as int8 rows
-    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3 && g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn;
+    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3 && g.KT == 4 && g.Lp == BLK_A_T;
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
         if (i8_path) {
             // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
-            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
+            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
             EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
             if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
         } else {
-            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
+            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
             EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, nullptr, 0, nullptr};
             if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
         }
@@ -336,7 +368,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // the fused kernel has one workgroup per (window, head): below ~one workgroup per CU the unfused pair
         // (12 projection blocks per window) spreads the same work over more CUs
         const bool i8 = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;
-        const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && g_fuse_attn && (i8 || nw * H >= 192);
+        const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && (i8 || nw * H >= 192);
         const bool fused_attn = attn_geom && !dbg_qkv;
         // the layer's output also as int8 slices when the next layer's attention kernel consumes them
         const bool q8_out = i8 && attn_geom && li + 1 < c->cfg.n_dec_layers;
@@ -344,7 +376,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         if (fused_attn && i8) {
             ProfScope ps(c, EGOEGO_K_QKV, s);
             AttnLayerArgs al{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, L.b_qkv, w.hA8, w.h_plane, w.hA_scale, w.O, w.o_plane, HD / 16,
-                             1.0f / sqrtf((float)c->cfg.d_k), H, g.L, w0 * H, g_ablate, g_trace};
+                             1.0f / sqrtf((float)c->cfg.d_k), H, g.L, w0 * H EG_DBG(, g_trace)};
             static bool once = false;
             if (!once) {
                 HIP_TRY(allow_smem(attn_layer_i8_kernel, AL_SMEM_BYTES));
@@ -355,7 +387,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         } else if (fused_attn) {
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)
             ProfScope ps(c, EGOEGO_K_QKV, s);
-            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0, g_ablate, g_trace};
+            GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0 EG_DBG(, g_ablate, g_trace)};
             auto kern = qkv_attn_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>, CfgQ<NP>, 4, NP>;
             constexpr int smem = CfgA<NP>::SMEM_BYTES > 2 * 4 * NP * 4096 ? CfgA<NP>::SMEM_BYTES : 2 * 4 * NP * 4096;
             static bool once = false;
@@ -369,7 +401,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             // --- Q, K, V projections (TM:71-73)
             {
                 ProfScope ps(c, EGOEGO_K_QKV, s);
-                GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
+                GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
                 auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
                 static bool once = false;
                 if (!once) {
@@ -387,16 +419,16 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             }
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_OUT) return 0;
-        if (g_fuse_tail && !small_ln && !last_dbg) {
+        if (!small_ln && !last_dbg) {
             // --- fused layer tail: fc+LN -> FFN-1 -> FFN-2+LN per 64-token block, two workgroups per CU (TM:92-93, 111-114, 135, 139)
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
             const int nb = rows / 64, b0 = row0 / 64;
-            GemmOperands g1{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, nb, b0, g_ablate, g_trace};
+            GemmOperands g1{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, nb, b0 EG_DBG(, g_ablate, g_trace)};
             EpiResLN<NP, 4, 64> e1{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
             // perf-debug: the three phases stamp disjoint parts of the trace buffer
-            GemmOperands g2{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, 1, nb, b0, g_ablate, g_trace ? g_trace + 4096 : nullptr};
+            GemmOperands g2{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, 1, nb, b0 EG_DBG(, g_ablate, g_trace ? g_trace + 4096 : nullptr)};
             EpiTiled<true, NP> e2{L.b_1, w.F, w.h_plane, N_MODEL / 16};
-            GemmOperands g3{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, nb, b0, g_ablate, g_trace ? g_trace + 8192 : nullptr};
+            GemmOperands g3{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, nb, b0 EG_DBG(, g_ablate, g_trace ? g_trace + 8192 : nullptr)};
             EpiResLN<NP, 4, 64> e3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
             auto kern = layer_tail_kernel<CfgBs<NP>, EpiResLN<NP, 4, 64>, EpiTiled<true, NP>>;
             static bool once = false;
@@ -412,9 +444,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         {
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
             if (small_ln) {
-                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
+                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
                 if (go.ntb <= SMALL_GRID) {
-                    GemmOperands gt{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 32, row0 / 32, g_ablate, g_trace};
+                    GemmOperands gt{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 32, row0 / 32 EG_DBG(, g_ablate, g_trace)};
                     EpiResLN<NP, 4, 32> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
                     if (int r = launch_gemm<CfgBt<NP>>(gt, e, s)) return r;
                 } else {
@@ -422,7 +454,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
                 }
             } else {
-                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+                GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, tb_b, t0_b EG_DBG(, g_ablate, g_trace)};
                 EpiResLN<NP, 4, 128> e{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
                 if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
             }
@@ -431,7 +463,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // --- FFN conv 1 + ReLU (TM:111)
         {
             ProfScope ps(c, EGOEGO_K_FFN1, s);
-            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, tb_a, t0_a, g_ablate, g_trace};
+            GemmOperands go{L.w_1, (size_t)N_MODEL * N_MODEL, w.hB, w.h_plane, N_MODEL / 16, N_MODEL / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
             EpiTiled<true, NP> e{L.b_1, w.F, w.h_plane, N_MODEL / 16};
             if (go.nfb * go.ntb <= SMALL_GRID) {
                 go.nfb = N_MODEL / 128;
@@ -443,9 +475,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         {
             ProfScope ps(c, EGOEGO_K_FFN2_LN, s);
             if (small_ln) {
-                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
+                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
                 if (go.ntb <= SMALL_GRID) {
-                    GemmOperands gt{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 32, row0 / 32, g_ablate, g_trace};
+                    GemmOperands gt{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 32, row0 / 32 EG_DBG(, g_ablate, g_trace)};
                     EpiResLN<NP, 4, 32> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
                     if (int r = launch_gemm<CfgBt<NP>>(gt, e, s)) return r;
                 } else {
@@ -453,7 +485,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
                 }
             } else {
-                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b, g_ablate, g_trace};
+                GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b EG_DBG(, g_ablate, g_trace)};
                 EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
                 if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
             }
@@ -462,29 +494,19 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     }
     if (io.run_out) {
         ProfScope ps(c, EGOEGO_K_OUT, s);
-        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c, g_ablate, g_trace};
+        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c EG_DBG(, g_ablate, g_trace)};
         EpiOut<NP> e{io.out};
         if (tb_c <= SMALL_GRID) {
-            GemmOperands gs{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64, g_ablate, g_trace};
+            GemmOperands gs{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
             if (int r = launch_gemm<CfgC2<NP>>(gs, e, s)) return r;
         } else if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
     }
     return 0;
 }
 
-// The batch is walked in chunks of windows, each chunk going through the WHOLE denoiser before the next
-// one starts: a chunk's intermediates (Q/K/V alone are 1.6 MB per window per layer) then stay in the
-// 256 MiB Infinity Cache between the kernel that writes them and the kernel that reads them.
 template <int NP>
 static int run_denoiser_np(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s) {
-    int chunk = g_chunk > 0 ? g_chunk : g.B;
-    const int per = 256 / g.Lp > 0 ? 256 / g.Lp : 1;  // windows per 256-row block
-    chunk = (chunk + per - 1) / per * per;
-    for (int w0 = 0; w0 < g.B; w0 += chunk) {
-        const int nw = (w0 + chunk < g.B) ? chunk : g.B - w0;
-        if (int r = run_chunk_np<NP>(c, g, w, io, s, w0, nw)) return r;
-    }
-    return 0;
+    return run_chunk_np<NP>(c, g, w, io, s, 0, g.B);
 }
 
 static int run_denoiser(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s) {
@@ -554,6 +576,7 @@ int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
         return fail(EGOEGO_E_INVALID, "unknown objective %d", cfg->objective);
     if (cfg->precision != EGOEGO_PREC_BF16X3 && cfg->precision != EGOEGO_PREC_BF16X1 && cfg->precision != EGOEGO_PREC_I8X3)
         return fail(EGOEGO_E_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->flags & ~EGOEGO_FLAG_NO_GRAPH) return fail(EGOEGO_E_INVALID, "unknown flags 0x%x", cfg->flags);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(EGOEGO_E_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -571,13 +594,24 @@ int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
     c->have_weights = c->have_sched = false;
     c->prof_id = -1;
     c->w_embed = c->w_out = nullptr;
+    c->cap_stream = nullptr;
     *out = c;
     return 0;
+}
+
+static void drop_graphs(egoego_ctx* c) {
+    for (StepGraph& g : c->graphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
+    c->graphs.clear();
 }
 
 void egoego_ctx_destroy(egoego_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    drop_graphs(c);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     for (void* p : c->allocs) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     delete c;
@@ -610,6 +644,7 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
     // (re)loading frees the previous copies after the stream drained
+    drop_graphs(c);  // captured steps hold the old weight pointers
     if (c->have_weights) {
         HIP_TRY(hipStreamSynchronize(s));
         for (void* p : c->allocs) (void)hipFree(p);
@@ -769,6 +804,54 @@ int egoego_p_sample(egoego_ctx* c, float* d_x, const float* d_xc, const int64_t*
     return run_denoiser(c, g, w, io, s);
 }
 
+// n_steps diffusion steps on `s`.  The first step of a configuration the context has not seen is launched directly
+// (this also sets the kernels' shared-memory attributes); one step is then captured into a hipGraph on the context's
+// own capture stream (nothing executes there) and the remaining steps are replays of that graph: 11 launches per
+// step become one hipGraphLaunch, which is what keeps small batches (latency-bound kernels) fed.
+static int run_steps(egoego_ctx* c, const Geometry& g, const Workspace& w, StepIO& io, const StepKey& key, int t_start,
+                     int n_steps, hipStream_t s) {
+    k_state_init<<<1, 1, 0, s>>>(w.state, t_start);
+    HIP_TRY(hipGetLastError());
+    const int* ts = key.ddim ? w.step_ts : nullptr;
+    auto one_step = [&](hipStream_t st) -> int {
+        k_step_begin<<<1, 256, 0, st>>>(w.state, ts, w.t_idx, g.B);
+        HIP_TRY(hipGetLastError());
+        return run_denoiser(c, g, w, io, st);
+    };
+    const bool graphs = !(c->cfg.flags & EGOEGO_FLAG_NO_GRAPH) && c->prof_id < 0;
+    int i = 0;
+    if (graphs && n_steps >= 2) {
+        StepGraph* sg = nullptr;
+        for (StepGraph& e : c->graphs)
+            if (e.key == key) sg = &e;
+        if (!sg) {
+            if (int r = one_step(s)) return r;
+            i = 1;
+            if (!c->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+            StepGraph e{};
+            e.key = key;
+            HIP_TRY(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed));
+            const int r = one_step(c->cap_stream);
+            const hipError_t ce = hipStreamEndCapture(c->cap_stream, &e.graph);
+            if (r) return r;
+            if (ce != hipSuccess) return fail(EGOEGO_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            HIP_TRY(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+            if (c->graphs.size() >= 8) {
+                (void)hipGraphExecDestroy(c->graphs.front().exec);
+                (void)hipGraphDestroy(c->graphs.front().graph);
+                c->graphs.erase(c->graphs.begin());
+            }
+            c->graphs.push_back(e);
+            sg = &c->graphs.back();
+        }
+        for (; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(sg->exec, s));
+        return 0;
+    }
+    for (; i < n_steps; ++i)
+        if (int r = one_step(s)) return r;
+    return 0;
+}
+
 int egoego_sample_loop(egoego_ctx* c, float* d_x, const float* d_xc, int t_start, int n_steps, const float* d_noise,
                        int noise_mode, uint64_t seed, int64_t window_offset, const float* d_prefix, int prefix_len,
                        int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
@@ -784,6 +867,7 @@ int egoego_sample_loop(egoego_ctx* c, float* d_x, const float* d_xc, int t_start
     Geometry g;
     Workspace w;
     if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    if (n_steps == 0) return 0;
     StepIO io{};
     // x and x_cond are split/packed ONCE; afterwards the posterior epilogue keeps the embed operand current.
     if (int r = pack_inputs(c, g, w, d_x, d_xc, nullptr, &io.row_mask, s)) return r;
@@ -793,19 +877,15 @@ int egoego_sample_loop(egoego_ctx* c, float* d_x, const float* d_xc, int t_start
     io.out.mode = 1;
     io.out.x = d_x;
     io.out.noise_mode = noise_mode;
+    io.out.noise = (noise_mode == EGOEGO_NOISE_INJECTED) ? d_noise : nullptr;
     io.out.seed = seed;
     io.out.window_offset = window_offset;
     io.out.prefix = d_prefix;
     io.out.prefix_len = d_prefix ? prefix_len : 0;
-    const size_t step_elems = (size_t)B * T * c->D;
-    for (int i = 0; i < n_steps; ++i) {
-        const int t = t_start - i;
-        k_fill_t<<<(B + 255) / 256, 256, 0, s>>>(w.t_idx, B, t);
-        HIP_TRY(hipGetLastError());
-        io.out.noise = (noise_mode == EGOEGO_NOISE_INJECTED) ? d_noise + (size_t)i * step_elems : nullptr;
-        if (int r = run_denoiser(c, g, w, io, s)) return r;
-    }
-    return 0;
+    io.out.state = w.state;
+    io.out.step_elems = (size_t)B * T * c->D;
+    const StepKey key{B, T, 1, noise_mode, io.out.prefix_len, 1, 0, d_x, io.out.noise, d_prefix, d_ws, seed, window_offset};
+    return run_steps(c, g, w, io, key, t_start, n_steps, s);
 }
 
 int egoego_ddim_loop(egoego_ctx* c, float* d_x, const float* d_xc, const int32_t* ts, int n, int B, int T, void* d_ws,
@@ -822,18 +902,22 @@ int egoego_ddim_loop(egoego_ctx* c, float* d_x, const float* d_xc, const int32_t
     if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
     StepIO io{};
     if (int r = pack_inputs(c, g, w, d_x, d_xc, nullptr, &io.row_mask, s)) return r;
+    // the timestep list and alphas_cumprod of each step's successor, read by the step kernels through the step index
+    HIP_TRY(hipStreamSynchronize(s));  // the staging vectors below may still feed a previous call's copies
+    c->ddim_ts_host.assign(ts, ts + n);
+    c->ddim_abar_host.resize(n);
+    for (int i = 0; i < n; ++i) c->ddim_abar_host[i] = (i + 1 < n) ? c->abar_host[ts[i + 1]] : 1.0f;
+    HIP_TRY(hipMemcpyAsync(w.step_ts, c->ddim_ts_host.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.step_abar, c->ddim_abar_host.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
     io.stop_layer = io.stop_stage = -1;
     io.run_out = true;
     base_out_params(c, g, w, io.out);
     io.out.mode = 2;
     io.out.x = d_x;
-    for (int i = 0; i < n; ++i) {
-        k_fill_t<<<(B + 255) / 256, 256, 0, s>>>(w.t_idx, B, ts[i]);
-        HIP_TRY(hipGetLastError());
-        io.out.ddim_abar_prev = (i + 1 < n) ? c->abar_host[ts[i + 1]] : 1.0f;
-        if (int r = run_denoiser(c, g, w, io, s)) return r;
-    }
-    return 0;
+    io.out.state = w.state;
+    io.out.abar_prev_tab = w.step_abar;
+    const StepKey key{B, T, 2, EGOEGO_NOISE_NONE, 0, 1, 1, d_x, nullptr, nullptr, d_ws, 0, 0};
+    return run_steps(c, g, w, io, key, 0, n, s);
 }
 
 int egoego_rot6d_to_matrix(const float* d_in, float* d_out, int64_t n, void* stream) {
@@ -892,12 +976,18 @@ int egoego_window_prefix(const float* d_aa, const float* d_root, const float* d_
     return 0;
 }
 
-/* perf-debug only (not in the public header): per-block timestamps of every GEMM launch go to `buf`
- * ([grid][4] u64, overwritten by each launch); nullptr disables. */
+#ifdef EGOEGO_PERFDEBUG
+/* perf-debug build only (not in the public header): per-block timestamps of every GEMM launch go to `buf`
+ * ([grid][4] u64, overwritten by each launch), nullptr disables; ablate bit 1 skips GEMM epilogues, bit 2 attention. */
 int egoego_debug_trace_buffer(unsigned long long* buf) {
     g_trace = buf;
     return 0;
 }
+int egoego_debug_ablate(int bits) {
+    g_ablate = bits;
+    return 0;
+}
+#endif
 
 int egoego_profile_begin(egoego_ctx* c, int kernel_id) {
     if (!c || kernel_id < 0 || kernel_id >= EGOEGO_K_COUNT) return fail(EGOEGO_E_INVALID, "bad kernel id");

@@ -24,6 +24,14 @@
 #ifndef EGOEGO_ABLATE_MAINLOOP
 #define EGOEGO_ABLATE_MAINLOOP 0
 #endif
+// Per-block timestamps and epilogue/attention ablation exist only in the perf-debug build
+// (`python -m egoego_release_amd.build --perfdebug` -> libegoego_hip_perfdebug.so, used by tools/*_trace.py);
+// the product library carries neither the fields nor the branches.
+#ifdef EGOEGO_PERFDEBUG
+#define EG_DBG(...) __VA_ARGS__
+#else
+#define EG_DBG(...)
+#endif
 
 struct GemmOperands {
     const __bf16* w;  // weights, fragment-tiled [N][K]; lo plane at w + w_plane
@@ -34,8 +42,8 @@ struct GemmOperands {
     int nfb;  // feature blocks in the grid
     int ntb;  // token blocks in the grid
     int tblk0;  // first token block of this launch (window-chunked launches)
-    int ablate;  // perf-debug only (EGOEGO_ABLATE): 2 = skip the epilogue, 4 = skip attention
-    unsigned long long* trace;  // perf-debug: [nblocks][4] = {t_start, t_mainloop_end, t_end, hw_id | xcc_id << 32} or nullptr
+    EG_DBG(int ablate;                  // 2 = skip the epilogue, 4 = skip attention
+           unsigned long long* trace;)  // [nblocks][4] = {t_start, t_mainloop_end, t_end, hw_id | xcc_id << 32} or nullptr
 };
 
 // Blocks that share an activation tile (same token block, different feature blocks) are made
@@ -120,12 +128,12 @@ struct GemmBody {
         const int wave = wave_id_uniform();
         const int lane = threadIdx.x & 63;
         const int wf = wave % C::NWF, wt = wave / C::NWF;
-        if (g.trace && threadIdx.x == 0) {
+        EG_DBG(if (g.trace && threadIdx.x == 0) {
             g.trace[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
             g.trace[65536 + (size_t)blockIdx.x * 2] = __builtin_readcyclecounter();
             g.trace[(size_t)blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-        }
+        })
 
         // Per-thread source pointers of this stage's chunks (wave-uniform base + lane).
         const u32x4* gp[NCH];
@@ -298,10 +306,10 @@ struct GemmBody {
             mfmas(a0, w1, 1, false, 0, 0, 0, nothing);
         }
         __syncthreads();
-        if (g.trace && threadIdx.x == 0) {
+        EG_DBG(if (g.trace && threadIdx.x == 0) {
             g.trace[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
             g.trace[65536 + (size_t)blockIdx.x * 2 + 1] = __builtin_readcyclecounter();
-        }
+        })
     }
 
     static __device__ void run(const GemmOperands& g, const Epi& epi, int fblk, int tblk, char* smem) {
@@ -312,15 +320,15 @@ struct GemmBody {
         const int wf = wave % C::NWF, wt = wave / C::NWF;
         const int f0 = (fblk * C::WT + wf * C::FT) * 32;
         const int t0 = (tblk * C::AT + wt * C::TT) * 32;
-        if (g.ablate & 2) {
+        EG_DBG(if (g.ablate & 2) {
             if (acc[0][0][0] == 123.456f) *(float*)smem = acc[C::FT - 1][C::TT - 1][7];  // keep the MFMAs alive
             return;
-        }
+        })
         epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
-        if (g.trace) {
+        EG_DBG(if (g.trace) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (threadIdx.x == 0) g.trace[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
-        }
+        })
     }
 };
 
@@ -773,8 +781,12 @@ struct OutParams {
     int objective;         // 1 = pred_x0
     const float* prefix;   // [B][prefix_len][D] or nullptr
     int prefix_len;
-    // DDIM (mode 2): x <- sqrt(abar_prev) * x0 + sqrt(1 - abar_prev) * eps, abar_prev given per call
-    float ddim_abar_prev;
+    // DDIM (mode 2): x <- sqrt(abar_prev) * x0 + sqrt(1 - abar_prev) * eps
+    const float* abar_prev_tab;  // [n] alphas_cumprod of each step's successor, indexed by the step index
+    // multi-step loops: state[0] - 1 is the index of the running step (device-resident so that one captured step
+    // replays for the whole chain); it selects the injected-noise slice and the DDIM table row.  nullptr: single step.
+    const int* state;
+    size_t step_elems;     // B*T*D: stride between the injected-noise slices of consecutive steps
     int Lp, T, B, D, DP;
 };
 
@@ -783,7 +795,7 @@ struct EpiOut {
     OutParams p;
     // one group = 4 consecutive features f..f+3 of one frame
     __device__ void group(const float (&o)[4], int f, int m, int b, int frame, size_t row, int t, float c1, float c2,
-                          float sigma, float srec, float srecm1, float abar) const {
+                          float sigma, float srec, float srecm1, float abar, const float* noise, float abar_prev) const {
         if (p.mode == 0) {
 #pragma unroll
             for (int c = 0; c < 4; c += 2)
@@ -803,7 +815,7 @@ struct EpiOut {
 #pragma unroll
                 for (int c = 0; c < 4; c += 2)
                     if (f + c < p.D) {
-                        const float2 v = *(const float2*)(p.noise + row + f + c);
+                        const float2 v = *(const float2*)(noise + row + f + c);
                         nz[c] = v.x;
                         nz[c + 1] = v.y;
                     }
@@ -821,7 +833,7 @@ struct EpiOut {
                 xn[c] = mean + sigma * nz[c];
             } else {  // DDIM, eta = 0
                 const float eps = (xt[c] - sqrtf(abar) * x0) / sqrtf(fmaxf(1.0f - abar, 1e-20f));
-                xn[c] = sqrtf(p.ddim_abar_prev) * x0 + sqrtf(fmaxf(1.0f - p.ddim_abar_prev, 0.f)) * eps;
+                xn[c] = sqrtf(abar_prev) * x0 + sqrtf(fmaxf(1.0f - abar_prev, 0.f)) * eps;
             }
             if (f + c >= p.D) xn[c] = 0.f;
         }
@@ -844,6 +856,9 @@ struct EpiOut {
     template <int FT, int TT>
     __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
         const int hf = lane >> 5, col = lane & 31;
+        const int step = p.state ? p.state[0] - 1 : 0;
+        const float* noise = p.noise ? p.noise + (size_t)step * p.step_elems : nullptr;
+        const float abar_prev = p.abar_prev_tab ? p.abar_prev_tab[step] : 1.0f;
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
@@ -867,7 +882,7 @@ struct EpiOut {
                         const float4 b4 = *(const float4*)(p.bias + f);
                         const float o[4] = {acc[i][j][4 * g + 0] + b4.x, acc[i][j][4 * g + 1] + b4.y,
                                             acc[i][j][4 * g + 2] + b4.z, acc[i][j][4 * g + 3] + b4.w};
-                        group(o, f, m, b, frame, row, t, c1, c2, sigma, srec, srecm1, abar);
+                        group(o, f, m, b, frame, row, t, c1, c2, sigma, srec, srecm1, abar, noise, abar_prev);
                     }
                 }
         }

@@ -122,9 +122,24 @@ __global__ void k_convert_t(const int64_t* __restrict__ t, int* __restrict__ out
     }
 }
 
-__global__ void k_fill_t(int* __restrict__ out, int B, int value) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) out[i] = value;
+// Step state of a multi-step loop, kept in device memory so that ONE captured step (hipGraph) replays for every
+// timestep: state[0] = steps begun, state[1] = timestep of the first step.  k_step_begin (one block) publishes the
+// current step's timestep for every window — t_start - i for the ancestral chain (M:267-268), ts[i] for a strided
+// list — and advances the counter; the step's kernels read state[0] - 1 as the index of the running step.
+__global__ void k_state_init(int* __restrict__ state, int t_start) {
+    state[0] = 0;
+    state[1] = t_start;
+}
+
+__global__ __launch_bounds__(256) void k_step_begin(int* __restrict__ state, const int* __restrict__ ts, int* __restrict__ t_idx, int B) {
+    __shared__ int t_sh;
+    if (threadIdx.x == 0) {
+        const int i = state[0];
+        t_sh = ts ? ts[i] : state[1] - i;
+        state[0] = i + 1;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 256) t_idx[b] = t_sh;
 }
 
 // Padding mask [B][T+1] -> one multiplier per padded token row.

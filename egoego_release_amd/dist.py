@@ -22,7 +22,7 @@ def gather_windows(local, n_windows, group=None):
     if world == 1:
         return local
     sizes = [shard_bounds(n_windows, r, world) for r in range(world)]
-    pad = max(hi - lo for lo, hi in sizes)
+    pad = max(1, max(hi - lo for lo, hi in sizes))
     buf = local
     if local.shape[0] < pad:  # uneven shards: pad to the largest so all_gather sees equal shapes
         buf = torch.cat((local, local.new_zeros(pad - local.shape[0], *local.shape[1:])), 0)
@@ -44,7 +44,12 @@ def sample_sharded(sample_fn, x_start, cond_mask, init_noise, group=None):
     B = x_start.shape[0]
     lo, hi = shard_bounds(B, rank, world)
     sl = slice(lo, hi)
-    local = sample_fn(x_start[sl], cond_mask[sl], {k: v[sl] for k, v in init_noise.items()}, lo)
+    if hi > lo:
+        local = sample_fn(x_start[sl], cond_mask[sl], {k: v[sl] for k, v in init_noise.items()}, lo)
+    else:
+        # fewer windows than ranks: this rank has nothing to sample but must still enter the collective
+        dev = next(iter(init_noise.values())).device if init_noise else x_start.device
+        local = torch.empty((0,) + tuple(x_start.shape[1:]), dtype=torch.float32, device=dev)
     return gather_windows(local, B, group) if world > 1 else local
 
 
@@ -60,6 +65,22 @@ def hip_sample_fn(model, seed=0):
         x_cond = (xs * (1.0 - cm) + cm * noise["cond"].to(dev)).float().contiguous()
         S = model.num_timesteps
         eng.sample_loop_(x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
+        return x
+
+    return fn
+
+
+def hip_steps_fn(model, t_start, n_steps, seed=0):
+    """Like hip_sample_fn, but `n_steps` ancestral steps from timestep `t_start` downwards (a slice of the chain):
+    what bench.py times."""
+    from . import _lib
+
+    def fn(xs, cm, noise, window_offset):
+        eng = model.hip_engine()
+        dev = model.betas.device
+        x = noise["x_T"].to(dev, torch.float32).contiguous().clone()
+        x_cond = (xs.to(dev) * (1.0 - cm.to(dev)) + cm.to(dev) * noise["cond"].to(dev)).float().contiguous()
+        eng.sample_loop_(x, x_cond, t_start, n_steps, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
         return x
 
     return fn

@@ -17,7 +17,7 @@ def _f32c(t, device):
 
 
 class HipEngine:
-    def __init__(self, cfg_dict, state_dict, device, precision=_lib.PREC_I8X3):
+    def __init__(self, cfg_dict, state_dict, device, precision=_lib.PREC_I8X3, flags=0):
         """cfg_dict: d_feats, d_model, n_head, n_dec_layers, d_k, d_v, max_timesteps, num_timesteps,
         objective ('pred_x0' | 'pred_noise').  state_dict: reference-layout tensors (any device)."""
         self.lib = _lib.load()
@@ -32,7 +32,7 @@ class HipEngine:
             raise ValueError(f"unknown objective {self.cfg['objective']}")
         c = _lib.Config(self.cfg["d_feats"], self.cfg["d_model"], self.cfg["n_head"], self.cfg["n_dec_layers"],
                         self.cfg["d_k"], self.cfg["d_v"], self.cfg["max_timesteps"], self.cfg["num_timesteps"],
-                        obj, precision)
+                        obj, precision, flags)
         self._ctx = C.c_void_p()
         _lib.check(self.lib.egoego_ctx_create(C.byref(c), self.dev_index, C.byref(self._ctx)))
         self._ws = {}

@@ -71,6 +71,36 @@ class SkeletonStats:
         return torch.cat(gr, dim=-2), torch.cat(gp, dim=-2) + root_trans[:, None, :]
 
 
+def _parents_of(ds, parents=None):
+    """The kinematic tree to use: an explicit argument, else `ds.parents` (SkeletonStats carries it; set it on any
+    other `ds` to override), else the first 22 entries of the SMPL-H kintree (SURVEY.md §8f #1: an input, not a constant)."""
+    if parents is None:
+        parents = getattr(ds, "parents", None)
+    return SMPLH_PARENTS_22 if parents is None else tuple(int(p) for p in parents)
+
+
+def _hip_stats(ds, *names):
+    """The statistics tensors of `ds` as flat fp32 lists when the per-window HIP kernels may stand in for ds's METHODS
+    (normalize / de_normalize / fk_smpl), else None (the torch chain then calls the methods).  The kernels implement
+    exactly SkeletonStats' and the reference AMASSDataset's methods, so they are used for those two types, or for any
+    `ds` that opts in with `ds.use_hip_harness = True`; a `ds` with methods of its own keeps them.  Shapes must match
+    the 22-joint layout (66 values each)."""
+    if not (isinstance(ds, SkeletonStats) or type(ds).__name__ == "AMASSDataset" or getattr(ds, "use_hip_harness", False)):
+        return None
+    if getattr(ds, "use_hip_harness", True) is False:
+        return None
+    out = []
+    for n in names:
+        v = getattr(ds, n, None)
+        if v is None:
+            return None
+        v = torch.as_tensor(v)
+        if v.numel() != 66:
+            return None
+        out.append(v)
+    return out
+
+
 def rotate_at_frame(trans, quat, cano_t_idx=0):
     """Heading canonicalisation on the device: rotate about z so that the facing direction of frame
     `cano_t_idx` projects onto +x.  trans [B,T,3], quat [B,T,4] -> (trans', quat', yrot [B,1,1,4])."""
@@ -101,14 +131,16 @@ def quat_ik(grot_mat, parents=SMPLH_PARENTS_22):
     return R.quaternion_to_matrix(res)
 
 
-def convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_head_jpos=None, parents=SMPLH_PARENTS_22):
+def convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_head_jpos=None, parents=None):
     """M:469-525: normalised window [B,T,198] -> (local axis-angle [B,T,22,3], root position [B,T,3],
     head position [B,T,3]) in the ORIGINAL (un-canonicalised) heading.  recover_rot_quat: [B,1,1,4]
     (tensor or numpy)."""
     bs = all_res_list.shape[0]
     dev = all_res_list.device
-    jmin, jmax = getattr(ds, "global_jpos_min", None), getattr(ds, "global_jpos_max", None)
-    if all_res_list.is_cuda and jmin is not None and jmax is not None and all_res_list.shape[-1] == 198:
+    parents = _parents_of(ds, parents)
+    st = _hip_stats(ds, "global_jpos_min", "global_jpos_max") if all_res_list.is_cuda and all_res_list.shape[-1] == 198 else None
+    if st is not None and len(parents) == 22:
+        jmin, jmax = st
         # one HIP kernel for the whole chain (egoego_convert_model_res); the torch expressions below are for CPU tensors
         from . import _lib
         lib = _lib.load()
@@ -140,10 +172,11 @@ def convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_he
 
 def _window_condition_hip(ds, head_jpos, head_jquat):
     """egoego_window_condition (rotate_at_frame + x_start assembly + normalisation in one HIP kernel, M:355-378) for ROCm tensors
-    when `ds` exposes its min/max statistics as tensors; None otherwise.  Returns (x_start [B,Tw,198], recover [B,1,1,4])."""
-    jmin, jmax = getattr(ds, "global_jpos_min", None), getattr(ds, "global_jpos_max", None)
-    if not head_jpos.is_cuda or jmin is None or jmax is None:
+    when the kernels may stand in for `ds` (_hip_stats); None otherwise.  Returns (x_start [B,Tw,198], recover [B,1,1,4])."""
+    st = _hip_stats(ds, "global_jpos_min", "global_jpos_max") if head_jpos.is_cuda else None
+    if st is None:
         return None
+    jmin, jmax = st
     from . import _lib
     lib = _lib.load()
     dev = head_jpos.device
@@ -158,12 +191,14 @@ def _window_condition_hip(ds, head_jpos, head_jquat):
     return x_start, rec.reshape(b, 1, 1, 4)
 
 
-def _window_prefix_hip(ds, aa, root, n_last, parents=SMPLH_PARENTS_22):
+def _window_prefix_hip(ds, aa, root, n_last, parents=None):
     """egoego_window_prefix (one HIP kernel for fk_smpl + rotate_at_frame + normalisation + 6D, M:399-467) when the tensors
-    live on a ROCm device and `ds` exposes its statistics as tensors; None otherwise (the torch chain then runs)."""
-    rest, jmin, jmax = (getattr(ds, n, None) for n in ("rest_human_offsets", "global_jpos_min", "global_jpos_max"))
-    if not aa.is_cuda or rest is None or jmin is None or jmax is None or n_last < 1 or n_last > aa.shape[1]:
+    live on a ROCm device and the kernels may stand in for `ds` (_hip_stats); None otherwise (the torch chain then runs)."""
+    parents = _parents_of(ds, parents)
+    st = _hip_stats(ds, "rest_human_offsets", "global_jpos_min", "global_jpos_max") if aa.is_cuda else None
+    if st is None or len(parents) != 22 or n_last < 1 or n_last > aa.shape[1]:
         return None
+    rest, jmin, jmax = st
     from . import _lib
     lib = _lib.load()
     dev = aa.device
@@ -180,13 +215,14 @@ def _window_prefix_hip(ds, aa, root, n_last, parents=SMPLH_PARENTS_22):
 
 @torch.no_grad()
 def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos, global_head_jquat, cond_mask,
-                                             noise=None, parents=SMPLH_PARENTS_22):
+                                             noise=None, parents=None):
     """M:329-467.  Windows of `model.seq_len` frames, stride seq_len-10; window k+1 is conditioned on the
     last 10 frames of window k, re-canonicalised, by overwriting its first 10 frames after every step.
 
     noise (tests): {'x_all': [B,T,D], 'cond': [per-window [B,Tw,D]], 'steps': [per-window [S,B,Tw,D]]}.
     """
-    eng = model.hip_engine()
+    eng = model.hip_engine(verify=True)
+    parents = _parents_of(ds, parents)
     device = model.betas.device
     b = shape[0]
     S = model.num_timesteps
@@ -228,8 +264,7 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
             eng.sample_loop_(curr_x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=model.philox_seed + w_idx,
                              prefix=pfx)
         else:
-            for i in reversed(range(S)):
-                eng.sample_loop_(curr_x, x_cond, i, 1, noise=torch.randn_like(curr_x)[None], prefix=pfx)
+            model._torch_rng_chain(eng, curr_x, x_cond, S, pfx)
         aa, root, head = convert_model_res_to_data(ds, curr_x, recover, cur_jpos, parents)
         if t_idx == 0:
             whole_aa, whole_root, whole_head = aa, root, head
@@ -262,20 +297,22 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
 
 
 @torch.no_grad()
-def sample_sliding_window_w_canonical(model, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None):
+def sample_sliding_window_w_canonical(model, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None,
+                                      parents=None):
     model.denoise_fn.eval()
     res = p_sample_loop_sliding_window_w_canonical(model, ds, x_start.shape, global_head_jpos, global_head_jquat,
-                                                   cond_mask, noise=noise)
+                                                   cond_mask, noise=noise, parents=parents)
     model.denoise_fn.train()
     return res
 
 
 @torch.no_grad()
-def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None):
+def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None, parents=None):
     """head_pose [B,T,7] = xyz + quaternion (w,x,y,z) -> (local axis-angle [B,T',22,3], root [B,T',3])."""
     jpos, jquat = head_pose[:, :, :3], head_pose[:, :, 3:]
     data = torch.zeros(head_pose.shape[0], head_pose.shape[1], 198, device=head_pose.device)
-    return sample_sliding_window_w_canonical(model, ds, jpos, jquat, data, prep_head_condition_mask(data), noise=noise)
+    return sample_sliding_window_w_canonical(model, ds, jpos, jquat, data, prep_head_condition_mask(data), noise=noise,
+                                             parents=parents)
 
 
 # ------------------------------------------------------------------------------------------ checkpoints

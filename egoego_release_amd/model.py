@@ -143,7 +143,7 @@ class _EngineSlot:
     """Holds the (non-copyable) HIP context; deep copies (ema_pytorch.EMA) start empty."""
 
     def __init__(self):
-        self.engine, self.key = None, None
+        self.engine, self.key, self.fingerprint = None, None, None
 
     def __deepcopy__(self, memo):
         return _EngineSlot()
@@ -152,7 +152,7 @@ class _EngineSlot:
         return {}
 
     def __setstate__(self, state):
-        self.engine, self.key = None, None
+        self.engine, self.key, self.fingerprint = None, None, None
 
 
 class CondGaussianDiffusion(nn.Module):
@@ -192,26 +192,71 @@ class CondGaussianDiffusion(nn.Module):
         # PREC_I8X3 (default): int8-slice attention kernel where the window fits it (96 < T+1 <= 128), split-bf16
         # elsewhere, ~1.3e-4 from the fp32 reference; PREC_BF16X3: split-bf16 everywhere, ~2.5e-5, ~20 % slower.
         self.hip_precision = _lib.PREC_I8X3
+        self.hip_graph = True        # replay one captured step per chain (hipGraph); False launches every kernel
         self.sampling_rng = "torch"  # "torch": reference RNG draw order; "philox": in-kernel, shard-invariant
         self.philox_seed = 0
         self._slot = _EngineSlot()
 
     # ------------------------------------------------------------------ HIP engine plumbing
-    def _engine_key(self):
-        dev = self.betas.device
-        return (str(dev), self.hip_precision, self.objective, int(self.betas.shape[0]),
-                tuple((p.data_ptr(), p._version) for p in self.denoise_fn.parameters()))
+    _SCHEDULE_BUFFERS = ("posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped",
+                         "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "alphas_cumprod")
 
-    def hip_engine(self):
-        """The HIP context for the module's current device/weights (packed lazily, re-packed when
-        parameters change or the module moves)."""
+    def _packed_tensors(self):
+        """Every tensor the HIP context holds a packed copy of: the denoiser's parameters, the frozen position table
+        and the schedule buffers the step kernels read."""
+        return list(self.denoise_fn.parameters()) + [getattr(self, n) for n in self._SCHEDULE_BUFFERS]
+
+    def _engine_key(self):
+        """Cheap (host-only) identity of the packed state.  In-place writes through `.data` (ema_pytorch's
+        `ma_params.data.copy_` / `.data.lerp_`) bump neither `data_ptr` nor `_version`: those are caught by
+        `_weights_fingerprint()` at chain-level entry points and by the `invalidate_engine()` hooks."""
+        dev = self.betas.device
+        return (str(dev), self.hip_precision, bool(self.hip_graph), self.objective, int(self.betas.shape[0]),
+                tuple((p.data_ptr(), p._version) for p in self._packed_tensors()))
+
+    @torch.no_grad()
+    def _weights_fingerprint(self):
+        """Device-side checksum of everything packed into the HIP context (two multi-tensor norms, one host sync):
+        detects ANY in-place update, however it was made."""
+        ts = [t.detach().float() for t in self._packed_tensors()]
+        n2 = torch.stack(torch._foreach_norm(ts, 2)).double()
+        n1 = torch.stack(torch._foreach_norm(ts, 1)).double()
+        w = torch.arange(1, len(ts) + 1, device=n2.device, dtype=torch.float64)
+        return ((n2 * w).sum().item(), (n1 / w).sum().item())
+
+    def invalidate_engine(self):
+        """Drop the packed copy of the weights: the next sampling call re-packs from the module's current tensors.
+        Called by load_state_dict / .to() / .cuda() / .half() etc.; call it yourself after writing weights through
+        `.data` if you then use the per-step API (`p_sample`, `denoise`), which does not checksum."""
+        if self._slot.engine is not None:
+            self._slot.engine.close()
+        self._slot.engine, self._slot.key, self._slot.fingerprint = None, None, None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_engine()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if "_slot" in self.__dict__:
+            self.invalidate_engine()
+        return out
+
+    def hip_engine(self, verify=False):
+        """The HIP context for the module's current device/weights (packed lazily, re-packed when parameters change
+        or the module moves).  verify=True (every chain-level entry point: sample, p_sample_loop, ddim_sample, the
+        sliding-window harness) additionally compares a device-side checksum of the weights with the one taken when
+        they were packed."""
         dev = self.betas.device
         if dev.type != "cuda":
             raise _lib.EgoEgoHipError(
                 "CondGaussianDiffusion sampling runs on the MI355X HIP path only: move the module to a ROCm "
                 f"device first (it is on {dev}); there is no CPU fallback")
         key = self._engine_key()
-        if self._slot.engine is None or self._slot.key != key:
+        fp = self._weights_fingerprint() if verify else None
+        stale = self._slot.engine is None or self._slot.key != key or (verify and self._slot.fingerprint != fp)
+        if stale:
             if self._slot.engine is not None:
                 self._slot.engine.close()
             d = self.denoise_fn
@@ -220,9 +265,20 @@ class CondGaussianDiffusion(nn.Module):
                        objective=self.objective)
             if self.objective not in ("pred_noise", "pred_x0"):
                 raise ValueError(f"unknown objective {self.objective}")
-            self._slot.engine = HipEngine(cfg, self.state_dict(), dev, self.hip_precision)
+            self._slot.engine = HipEngine(cfg, self.state_dict(), dev, self.hip_precision,
+                                          0 if self.hip_graph else _lib.FLAG_NO_GRAPH)
             self._slot.key = key
+            self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
         return self._slot.engine
+
+    def _check_t(self, t):
+        """The reference indexes its schedule buffers with t (`extract`, M:36-39) and the time embedding accepts any
+        value; an out-of-range timestep raises there (index error / device assert).  Same here, before the kernels
+        (which clamp) see it."""
+        lo, hi = int(t.min()), int(t.max())
+        n = int(self.betas.shape[0])
+        if lo < 0 or hi >= n:
+            raise IndexError(f"timestep out of range: got [{lo}, {hi}], schedule has {n} steps")
 
     @staticmethod
     def _f32c(t):
@@ -242,6 +298,7 @@ class CondGaussianDiffusion(nn.Module):
     @torch.no_grad()
     def denoise(self, x, t, x_cond, padding_mask=None):
         """denoise_fn(cat(x, x_cond), t) on the HIP path."""
+        self._check_t(t)
         return self.hip_engine().denoise(self._f32c(x), self._f32c(x_cond), t.long().contiguous(), padding_mask)
 
     def p_mean_variance(self, x, t, x_cond, clip_denoised, padding_mask=None):
@@ -261,6 +318,7 @@ class CondGaussianDiffusion(nn.Module):
         """One ancestral step (fused on the GPU).  `noise=None` draws torch.randn_like(x), exactly
         where the reference draws it."""
         eng = self.hip_engine()
+        self._check_t(t)
         if noise is None:
             noise = torch.randn_like(x)
         out = self._f32c(x).clone()
@@ -276,7 +334,7 @@ class CondGaussianDiffusion(nn.Module):
         consumed in the reference's order (sampling_rng='torch') or the per-step noise is drawn in-kernel
         (sampling_rng='philox').
         """
-        eng = self.hip_engine()
+        eng = self.hip_engine(verify=True)
         device = self.betas.device
         S = self.num_timesteps
         if noise is not None:
@@ -301,11 +359,25 @@ class CondGaussianDiffusion(nn.Module):
         elif self.sampling_rng == "philox":
             eng.sample_loop_(x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=self.philox_seed, prefix=pfx)
         elif self.sampling_rng == "torch":
-            for i in reversed(range(S)):
-                eng.sample_loop_(x, x_cond, i, 1, noise=torch.randn_like(x)[None], prefix=pfx)
+            self._torch_rng_chain(eng, x, x_cond, S, pfx)
         else:
             raise ValueError(f"unknown sampling_rng {self.sampling_rng}")
         return x
+
+    @staticmethod
+    def _torch_rng_chain(eng, x, x_cond, S, prefix=None):
+        """The S ancestral steps with torch's generator consumed exactly as the reference consumes it — one
+        `randn_like(x)` per step, t = S-1 .. 0 (M:253, 267-268) — but drawn a chunk of steps ahead into one buffer
+        that a single call of the HIP loop then walks: the draws are the same `normal_` launches on the same shape
+        in the same order, only no longer interleaved with the steps, so the embed operand is packed once per chunk
+        instead of once per step and the steps of a chunk replay as one captured graph."""
+        chunk = max(1, min(S, (1 << 28) // max(1, x.numel())))
+        buf = torch.empty((chunk,) + tuple(x.shape), device=x.device, dtype=torch.float32)
+        for s0 in range(0, S, chunk):
+            n = min(chunk, S - s0)
+            for j in range(n):
+                buf[j].normal_()
+            eng.sample_loop_(x, x_cond, S - 1 - s0, n, noise=buf[:n], prefix=prefix)
 
     @torch.no_grad()
     def sample(self, x_start, cond_mask, padding_mask=None, noise=None):
@@ -319,7 +391,7 @@ class CondGaussianDiffusion(nn.Module):
     def ddim_sample(self, x_start, cond_mask, n_steps=50, noise=None):
         """Deterministic DDIM (eta=0) on a uniform stride of the training timesteps.  Not part of the
         reference (it only has the full ancestral chain); provided for BASELINE config 4."""
-        eng = self.hip_engine()
+        eng = self.hip_engine(verify=True)
         device = self.betas.device
         if noise is not None:
             x, cn = self._f32c(noise["x_T"].to(device)).clone(), noise["cond"].to(device)
@@ -336,16 +408,19 @@ class CondGaussianDiffusion(nn.Module):
         return harness.convert_model_res_to_data(ds, all_res_list, recover_rot_quat, curr_global_head_jpos)
 
     @torch.no_grad()
-    def p_sample_loop_sliding_window_w_canonical(self, ds, shape, global_head_jpos, global_head_jquat, cond_mask, noise=None):
+    def p_sample_loop_sliding_window_w_canonical(self, ds, shape, global_head_jpos, global_head_jquat, cond_mask, noise=None,
+                                                 parents=None):
         from . import harness
         return harness.p_sample_loop_sliding_window_w_canonical(self, ds, shape, global_head_jpos, global_head_jquat,
-                                                                cond_mask, noise=noise)
+                                                                cond_mask, noise=noise, parents=parents)
 
     @torch.no_grad()
-    def sample_sliding_window_w_canonical(self, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None):
+    def sample_sliding_window_w_canonical(self, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None,
+                                          parents=None):
+        """`parents` (or `ds.parents`) overrides the SMPL-H kintree the conversion chain walks (SURVEY.md §8f #1)."""
         from . import harness
         return harness.sample_sliding_window_w_canonical(self, ds, global_head_jpos, global_head_jquat, x_start, cond_mask,
-                                                         noise=noise)
+                                                         noise=noise, parents=parents)
 
     # ------------------------------------------------------------------ training half (plain PyTorch)
     def q_sample(self, x_start, t, noise=None):

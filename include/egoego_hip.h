@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define EGOEGO_ABI_VERSION 1
+#define EGOEGO_ABI_VERSION 2
 
 enum {
     EGOEGO_OK = 0,
@@ -60,7 +60,12 @@ typedef struct {
     int32_t num_timesteps;  /* diffusion steps S, 1000 */
     int32_t objective;      /* EGOEGO_PRED_X0 | EGOEGO_PRED_NOISE */
     int32_t precision;      /* EGOEGO_PREC_BF16X3 | EGOEGO_PREC_BF16X1 | EGOEGO_PREC_I8X3 */
+    int32_t flags;          /* EGOEGO_FLAG_* (0 = defaults) */
 } egoego_config;
+
+/* egoego_sample_loop / egoego_ddim_loop capture one diffusion step into a hipGraph and replay it for the rest of the
+ * chain (the timestep lives in device memory); this flag launches every kernel of every step individually instead. */
+enum { EGOEGO_FLAG_NO_GRAPH = 1 };
 
 /* fp32 device tensors in the reference checkpoint layout, contiguous. */
 typedef struct {

@@ -3,6 +3,7 @@ sampler, and all_gather; the result must equal the single-process result (shard 
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -43,7 +44,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    for B in (8, 7):  # even and ragged shards
+    for B in (8, 7, 1):  # even and ragged shards, and fewer windows than ranks (one rank samples nothing)
         out = str(tmp_path / f"r{B}.pt")
         mp.spawn(_worker, args=(2, port, B, out), nprocs=2, join=True)
         g = torch.Generator().manual_seed(0)
@@ -52,3 +53,32 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         noise = {"x_T": torch.randn(B, 6, 10, generator=g), "cond": torch.randn(B, 6, 10, generator=g)}
         want = _fake_sampler(xs, cm, noise, 0)
         assert torch.equal(torch.load(out), want)
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_one_rank_bit_for_bit(tmp_path):
+    """The N > 1 path of bench.py on real kernels: two gloo ranks share the one GPU of the test box, each samples its
+    half of a 64-window batch through dist.sample_sharded / hip_steps_fn (in-kernel Philox keyed by the GLOBAL window
+    index) and the gathered poses must equal the single-rank run bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EGOEGO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "6", "--warmup", "2", "--batch", "64", "--no-cpu-baseline"]
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump", one] + common, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dump", two]
+                        + common, env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    line = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["windows_per_gpu"] == 32
+    a, b = torch.load(one), torch.load(two)
+    assert a.shape == (64, 120, 198) and torch.equal(a, b)

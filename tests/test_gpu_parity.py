@@ -328,3 +328,84 @@ def test_outlier_heavy_weights_stay_within_the_bar(prec):
     got = m.denoise(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda()).cpu()
     err = (got - want).abs().max().item()
     assert err < (1e-4 if prec == _lib.PREC_BF16X3 else 6e-4), err
+
+
+def test_graph_replay_equals_individual_launches(prec):
+    """egoego_sample_loop captures one step into a hipGraph and replays it (timestep and step index live in device
+    memory); the result must be bit-identical to launching every kernel of every step, for Philox and for injected
+    noise, with prefix in-painting, across repeated calls that reuse the cached graph, and for the DDIM loop."""
+    B, T, S = 5, 120, 9
+    xs, cm = make_head_windows(B, T, seed=2)
+    g = torch.Generator().manual_seed(6)
+    x0 = torch.randn(xs.shape, generator=g).cuda()
+    xc = (xs * (1 - cm) + cm * torch.randn(xs.shape, generator=g)).cuda()
+    nz = torch.randn(S, B, T, 198, generator=g).cuda()
+    pre = (torch.rand(B, 10, 198, generator=g) * 2 - 1).cuda()
+    res = {}
+    for graph in (True, False):
+        cfg, sd, m = _model(precision=prec)
+        m.hip_graph = graph
+        eng = m.hip_engine()
+        out = []
+        for rep in range(2):  # the second round hits the graph cache
+            a = x0.clone()
+            eng.sample_loop_(a, xc, 999, S, noise_mode=_lib.NOISE_PHILOX, seed=3)
+            b = x0.clone()
+            eng.sample_loop_(b, xc, 400, S, noise=nz, prefix=pre)
+            c = x0.clone()
+            eng.ddim_loop_(c, xc, [900, 700, 500, 300, 100, 0])
+            out += [a, b, c]
+        assert torch.equal(out[0], out[3]) and torch.equal(out[1], out[4]) and torch.equal(out[2], out[5])
+        res[graph] = out[:3]
+    for u, v in zip(res[True], res[False]):
+        assert torch.equal(u, v)
+
+
+def test_default_torch_rng_path_draws_like_the_reference():
+    """sampling_rng='torch' (the drop-in default): after torch.manual_seed(s), sample() consumes the device generator
+    exactly as the reference's loop does — x_T, condition noise, then one randn_like(x) per step, t = S-1 .. 0
+    (M:263-268) — although the draws are made a chunk of steps ahead.  Checked against the same draws made by hand
+    and fed through p_sample step by step."""
+    cfg, sd, m = _model()
+    S, B, T = 7, 3, 120
+    m.num_timesteps = S
+    xs, cm = make_head_windows(B, T, seed=4)
+    xs, cm = xs.cuda(), cm.cuda()
+    torch.manual_seed(77)
+    got = m.sample(xs, cm)
+    torch.manual_seed(77)
+    x = torch.randn(xs.shape, device="cuda")
+    xc = xs * (1.0 - cm) + cm * torch.randn_like(xs)
+    for i in reversed(range(S)):
+        x = m.p_sample(x, torch.full((B,), i, device="cuda", dtype=torch.long), xc)  # draws randn_like(x) itself
+    assert torch.equal(got, x)
+
+
+def test_in_place_weight_update_is_picked_up():
+    """`p.data.copy_` (ema_pytorch) changes neither data_ptr nor _version; sample() must still use the new
+    weights (device-side fingerprint), and invalidate_engine() serves the per-step API."""
+    cfg, sd, m = _model()
+    xs, cm = make_head_windows(2, 120, seed=9)
+    m.num_timesteps = 3
+    nz = _ref_noise(xs.shape, 3)
+    a = m.sample(xs.cuda(), cm.cuda(), noise=nz)
+    w = m.denoise_fn.linear_out.weight
+    w.data.copy_(w.data * 0.5)
+    b = m.sample(xs.cuda(), cm.cuda(), noise=nz)
+    assert not torch.equal(a, b)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["denoise_fn.linear_out.weight"] = sd["denoise_fn.linear_out.weight"] * 0.5
+    with torch.no_grad():
+        x = nz["x_T"].clone()
+        xc = xs * (1 - cm) + cm * nz["cond"]
+        for i, t in enumerate((2, 1, 0)):
+            x = O.p_sample(sd2, O.make_schedule(1000), x, torch.full((2,), t), xc, nz["steps"][i])
+    assert (b.cpu() - x).abs().max().item() < POSE_TOL
+    t = torch.zeros(2, dtype=torch.long, device="cuda")
+    y0 = m.denoise(xs.cuda(), t, xs.cuda())
+    w.data.mul_(2.0)
+    m.invalidate_engine()
+    y1 = m.denoise(xs.cuda(), t, xs.cuda())
+    assert not torch.equal(y0, y1)
+    with pytest.raises(IndexError, match="out of range"):
+        m.denoise(xs.cuda(), t + 1000, xs.cuda())

@@ -88,17 +88,23 @@ def test_convert_model_res_to_data_cpu_vs_oracle():
 def test_sliding_window_hip_vs_oracle():
     """Two overlapping windows (40 + 20 frames at seq_len 40), 6 diffusion steps, identical injected noise:
     exercises canonicalisation, the per-step prefix in-painting inside the HIP loop, the conversion chain,
-    stitching and FK-based re-canonicalisation."""
+    stitching and FK-based re-canonicalisation on a synthetic skeleton.  The output head is 'trained-like' (bias = a
+    valid pose with orthonormal 6D rotations, small weight) so that M:493's Gram-Schmidt is well-conditioned and the
+    comparison with the numpy/scipy oracle can be tight; tests/test_harness_golden.py runs the reference's real demo
+    trajectory and statistics through the same path, and its per-kernel tests compare each HIP kernel with the oracle."""
     from egoego_release_amd.model import CondGaussianDiffusion
     seq_len, S, B, T = 40, 6, 2, 50
     cfg = ModelConfig(max_timesteps=seq_len + 1)
     sd = make_weights(cfg, 0)
+    rng = np.random.default_rng(11)
+    pose = np.concatenate([rng.uniform(-0.5, 0.5, 66), HO.quat_to_mat(_rand_quat((22,), 40))[:, :2, :].reshape(132)])
+    sd["denoise_fn.linear_out.bias"] = torch.from_numpy(pose).float()
+    sd["denoise_fn.linear_out.weight"] = sd["denoise_fn.linear_out.weight"] * 0.05
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
     m.load_state_dict(sd, strict=False)
     m = m.cuda()
     m.num_timesteps = S
     ds, dso = _skeleton(2)
-    rng = np.random.default_rng(11)
     head_q = _rand_quat((B, T), 12)
     head_p = np.cumsum(rng.standard_normal((B, T, 3)) * 0.01, 1) + np.array([0.0, 0.0, 1.5])
     head_pose = torch.from_numpy(np.concatenate([head_p, head_q], -1)).float()
@@ -112,80 +118,7 @@ def test_sliding_window_hip_vs_oracle():
     cm = O.head_condition_mask((B, T, 198))
     aa2, root2 = HO.sliding_window(sd, O.make_schedule(1000), dso, seq_len, S, head_pose[..., :3].double().numpy(),
                                    head_pose[..., 3:].double().numpy(), cm, noise)
-    assert np.abs(root.cpu().numpy() - root2).max() < 2e-3
-    d = Rot.from_rotvec(aa.reshape(-1, 3).cpu().numpy()) * Rot.from_rotvec(aa2.reshape(-1, 3)).inv()
+    assert np.abs(root.cpu().numpy() - root2).max() < 2e-4
+    d = Rot.from_rotvec(aa.reshape(-1, 3).cpu().numpy().astype(np.float64)) * Rot.from_rotvec(aa2.reshape(-1, 3)).inv()
     ang = np.abs(d.magnitude())
-    assert np.median(ang) < 1e-3 and np.quantile(ang, 0.99) < 2e-2, (np.median(ang), np.quantile(ang, 0.99), ang.max())
-
-
-@pytest.mark.gpu
-def test_convert_model_res_hip_kernel_vs_torch_chain():
-    """egoego_convert_model_res (one HIP kernel for M:469-525 + quat_ik) against the torch chain of the same module run on
-    CPU tensors, which test_convert_model_res_to_data_cpu_vs_oracle pins to the numpy/scipy restatement."""
-    g = torch.Generator().manual_seed(31)
-    B, T = 3, 37
-    x = torch.rand(B, T, 198, generator=g) * 2 - 1
-    rec = torch.nn.functional.normalize(torch.randn(B, 4, generator=g), dim=-1).reshape(B, 1, 1, 4)
-    lo = -torch.rand(66, generator=g) - 0.5
-    hi = torch.rand(66, generator=g) + 0.5
-    ds = harness.SkeletonStats(lo, hi, torch.randn(22, 3, generator=g))
-    want = harness.convert_model_res_to_data(ds, x, rec)
-    got = harness.convert_model_res_to_data(ds, x.cuda(), rec.cuda())
-    for w, g_, name in zip(want, got, ("axis-angle", "root", "head")):
-        assert g_.is_cuda and g_.shape == w.shape
-        assert (g_.cpu() - w).abs().max().item() < 2e-5, name
-    # the same rotations, compared as matrices (insensitive to the axis-angle branch near pi)
-    from egoego_release_amd import rotations as R
-    assert (R.axis_angle_to_matrix(got[0].cpu()) - R.axis_angle_to_matrix(want[0])).abs().max().item() < 1e-5
-    with pytest.raises(Exception, match="earlier joint"):
-        harness.convert_model_res_to_data(ds, x.cuda(), rec.cuda(), parents=(-1,) + (5,) * 21)
-
-
-@pytest.mark.gpu
-def test_window_prefix_hip_kernel_vs_torch_chain():
-    """egoego_window_prefix (fk_smpl + rotate_at_frame + normalisation + 6D in one HIP kernel, M:399-467) against the torch
-    chain the harness runs for CPU tensors."""
-    g = torch.Generator().manual_seed(77)
-    B, Tw, n_last = 3, 23, 10
-    aa = torch.randn(B, Tw, 22, 3, generator=g) * 0.7
-    aa[0, :, 5] = 0.0            # zero rotation: the small-angle branch
-    root = torch.randn(B, Tw, 3, generator=g)
-    lo, hi = -torch.rand(66, generator=g) - 1.5, torch.rand(66, generator=g) + 1.5
-    ds = harness.SkeletonStats(lo, hi, torch.randn(22, 3, generator=g) * 0.2)
-    got = harness._window_prefix_hip(ds, aa.cuda(), root.cuda(), n_last)
-    assert got is not None and got.shape == (B, n_last, 198)
-    # the torch chain, as written in p_sample_loop_sliding_window_w_canonical
-    gq, gj = ds.fk_smpl(root.reshape(-1, 3), aa.reshape(-1, 22, 3))
-    gq = gq.reshape(B, -1, 22, 4)[:, -n_last:]
-    gj = gj.reshape(B, -1, 22, 3)[:, -n_last:]
-    t_trans, _, t_rec = harness.rotate_at_frame(gj[:, :, harness.HEAD_IDX, :], gq[:, :, harness.HEAD_IDX, :], 0)
-    t_move = t_trans[:, 0:1, :].clone()
-    t_move[:, :, 2] = 0
-    inv = R.quaternion_invert(t_rec.float()).expand(B, n_last, 22, 4)
-    pj = R.quaternion_apply(inv, gj) - t_move[:, :, None, :]
-    pj = ds.normalize_jpos_min_max(pj.reshape(-1, 22, 3)).reshape(B, -1, 66)
-    p6 = R.matrix_to_rotation_6d(R.quaternion_to_matrix(R.quaternion_multiply(inv, gq))).reshape(B, -1, 132)
-    want = torch.cat((pj, p6), dim=-1)
-    assert (got.cpu() - want).abs().max().item() < 2e-5
-    assert harness._window_prefix_hip(ds, aa, root, n_last) is None  # CPU tensors: the torch chain is used
-
-
-@pytest.mark.gpu
-def test_window_condition_hip_kernel_vs_torch_chain():
-    """egoego_window_condition against the torch expressions of the harness (rotate_at_frame etc., M:355-378)."""
-    g = torch.Generator().manual_seed(12)
-    B, Tw = 4, 57
-    jpos = torch.randn(B, Tw, 3, generator=g)
-    jquat = torch.nn.functional.normalize(torch.randn(B, Tw, 4, generator=g), dim=-1)
-    lo, hi = -torch.rand(66, generator=g) - 1.5, torch.rand(66, generator=g) + 1.5
-    ds = harness.SkeletonStats(lo, hi, torch.zeros(22, 3))
-    x_start, rec = harness._window_condition_hip(ds, jpos.cuda(), jquat.cuda())
-    al_trans, al_quat, recover = harness.rotate_at_frame(jpos, jquat, 0)
-    move0 = al_trans[:, 0:1, :].clone()
-    move0[:, :, 2] = 0
-    want = torch.zeros(B, Tw, 198)
-    want[:, :, 45:48] = al_trans - move0
-    want[:, :, 66 + 90:66 + 96] = R.matrix_to_rotation_6d(R.quaternion_to_matrix(al_quat))
-    want[:, :, :66] = ds.normalize_jpos_min_max(want[:, :, :66].reshape(-1, 22, 3)).reshape(B, -1, 66)
-    assert (x_start.cpu() - want).abs().max().item() < 1e-5
-    assert (rec.cpu() - recover).abs().max().item() < 1e-6 and rec.shape == recover.shape
+    assert ang.max() < 1e-3, (np.median(ang), ang.max())

@@ -248,9 +248,11 @@ def test_demo_trajectory_through_gpu_harness(hg):
     assert np.abs(root - root2).max() < 1e-4, np.abs(root - root2).max()
     ang = _angle(aa, aa2)
     assert ang.max() < 1e-3, (ang.max(), np.median(ang))
-    # equivariance: row 1 is row 0 rotated about z and shifted (root orientation composes with the rotation, the other
-    # joints' local rotations are unchanged)
-    r0 = HO.quat_mul_vec(np.broadcast_to(zrot, (T, 4)), root[0].astype(np.float64)) + np.array([0.7, -0.4, 0.0])
+    # equivariance: row 1 is row 0 rotated about z (root orientation composes with the rotation, the other joints'
+    # local rotations are unchanged).  The xy shift does NOT come back: like the reference, convert_model_res_to_data
+    # un-rotates the canonical window (M:498-501) but never restores the translation that moved the head to the
+    # origin (M:369-373), so both rows live in a frame centred on their own first head position.
+    r0 = HO.quat_mul_vec(np.broadcast_to(zrot, (T, 4)), root[0].astype(np.float64))
     assert np.abs(r0 - root[1]).max() < 2e-4
     assert _angle(aa[0, :, 1:], aa[1, :, 1:]).max() < 1e-3
     rot0 = Rot.from_quat(np.array([[0.0, 0.0, np.sin(0.55), np.cos(0.55)]])) * Rot.from_rotvec(aa[0, :, 0].astype(np.float64))

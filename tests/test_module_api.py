@@ -95,3 +95,45 @@ def test_reference_checkpoint_format_loads(tmp_path):
     m3, _ = harness.load_stage2_checkpoint(str(path), use_ema=False)
     assert torch.equal(m3.state_dict()["denoise_fn.linear_out.bias"], full["denoise_fn.linear_out.bias"])
     assert m2.seq_len == 120 and m2.objective == "pred_x0" and m2.num_timesteps == 1000
+
+
+def test_weight_updates_through_data_are_detected():
+    """ema_pytorch writes the EMA weights with `ma_params.data.copy_` / `.data.lerp_`, which bump neither
+    `data_ptr` nor `_version`: the cheap key cannot see them, the device-side fingerprint every chain-level entry
+    point takes must, and load_state_dict / .to() drop the packed copy explicitly."""
+    cfg, m, sd = _model()
+    key, fp = m._engine_key(), m._weights_fingerprint()
+    p = m.denoise_fn.linear_out.weight
+    p.data.lerp_(torch.zeros_like(p), 0.01)
+    assert m._engine_key() == key            # the blind spot ...
+    assert m._weights_fingerprint() != fp    # ... that the fingerprint covers
+    fp = m._weights_fingerprint()
+    m.posterior_mean_coef1.data.mul_(1.001)  # schedule buffers are packed too
+    assert m._weights_fingerprint() != fp
+
+    class Eng:
+        closed = False
+
+        def close(self):
+            self.closed = True
+
+    e = Eng()
+    m._slot.engine, m._slot.key = e, key
+    m.load_state_dict(sd, strict=False)
+    assert e.closed and m._slot.engine is None
+    e2 = Eng()
+    m._slot.engine = e2
+    m.double()
+    assert e2.closed and m._slot.engine is None
+    m.float()
+    m2 = copy.deepcopy(m)
+    assert m2._slot.engine is None and m2._slot.fingerprint is None
+
+
+def test_timestep_range_is_checked_like_the_reference():
+    cfg, m, sd = _model()
+    with pytest.raises(IndexError, match="out of range"):
+        m._check_t(torch.tensor([3, 1000]))
+    with pytest.raises(IndexError, match="out of range"):
+        m._check_t(torch.tensor([-1]))
+    m._check_t(torch.tensor([0, 999]))

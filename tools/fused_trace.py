@@ -8,6 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egoego_release_amd import ModelConfig, make_weights, _lib
+from egoego_release_amd import _lib as _eglib
+_eglib.use_perfdebug_build()  # needs `python -m egoego_release_amd.build --perfdebug`
 from egoego_release_amd.model import CondGaussianDiffusion
 
 B, T = 256, 120
