@@ -56,13 +56,14 @@ class EgoEgoHipError(RuntimeError):
     pass
 
 
-def use_perfdebug_build():
-    """tools/*_trace.py only: bind the perf-debug build (per-block timestamps, stage ablation) instead of the product
-    library.  Must be called before the first load()."""
+def use_perfdebug_build(tag=None):
+    """tools/*_trace.py only: bind the perf-debug build (per-block timestamps, stage ablation; `tag` selects a variant
+    built with `build --perfdebug --tag=X -D...`) instead of the product library.  Must be called before the first load()."""
     global LIB_PATH
     if _lib is not None:
         raise EgoEgoHipError("use_perfdebug_build() must be called before the library is loaded")
-    LIB_PATH = PERFDEBUG_LIB_PATH
+    tag = tag if tag is not None else os.environ.get("EGOEGO_PERFDEBUG_TAG", "")
+    LIB_PATH = PERFDEBUG_LIB_PATH.replace(".so", f"_{tag}.so") if tag else PERFDEBUG_LIB_PATH
 
 
 def load():

@@ -25,13 +25,13 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False, perfdebug=False, defines=()):
+def build(force=False, verbose=False, perfdebug=False, defines=(), tag=""):
     """Compile csrc/*.hip -> egoego_release_amd/libegoego_hip.so (gfx950 only).
 
     perfdebug=True builds libegoego_hip_perfdebug.so instead: the same sources with -DEGOEGO_PERFDEBUG (per-block
     timestamps, stage ablation; plus any extra `defines` such as EGOEGO_ABLATE_MAINLOOP=1) for tools/*_trace.py.
     The product library contains none of that."""
-    out = LIB.replace(".so", "_perfdebug.so") if perfdebug else LIB
+    out = LIB.replace(".so", "_perfdebug" + (f"_{tag}" if tag else "") + ".so") if perfdebug else LIB
     if not force and not perfdebug and not is_stale():
         return out
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out]
@@ -46,4 +46,5 @@ def build(force=False, verbose=False, perfdebug=False, defines=()):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, perfdebug="--perfdebug" in sys.argv,
-                defines=[a[2:] for a in sys.argv if a.startswith("-D")]))
+                defines=[a[2:] for a in sys.argv if a.startswith("-D")],
+                tag=next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), "")))

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "pointwise.h"
+#include "tail_fused.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -320,6 +321,22 @@ static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
     return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
 }
 
+// Fused small-batch tail (tail_fused.h): 64-token workgroups while they fill the CUs at least once, 32-token ones below.
+static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        HIP_TRY(allow_smem(tail_kernel<2>, tail_smem_bytes(2)));
+        HIP_TRY(allow_smem(tail_kernel<1>, tail_smem_bytes(1)));
+        once = true;
+    }
+    if (rows / 64 >= 256)
+        tail_kernel<2><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
+    else
+        tail_kernel<1><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ the step
 struct StepIO {
     const float* row_mask;  // packed [Mp] or nullptr
@@ -419,6 +436,25 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             }
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_OUT) return 0;
+        if constexpr (NP == 2) {
+            if (tb_b <= 128) {
+                // --- small batches (at most one 64-token workgroup per CU): fc+LN -> FFN-1 -> FFN-2+LN in one latency-optimised kernel (tail_fused.h), same arithmetic
+                ProfScope ps(c, EGOEGO_K_FC_LN, s);
+                TailArgs ta{};
+                ta.o = w.O; ta.o_plane = w.o_plane; ta.HD16 = HD / 16;
+                ta.wfc = L.w_fc; ta.wfc_plane = (size_t)N_MODEL * HD;
+                ta.ln1 = EpiResLN<2, 4, 0>{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f, nullptr, 0, nullptr};
+                ta.w1 = L.w_1; ta.w1_plane = (size_t)N_MODEL * N_MODEL;
+                ta.relu = EpiTiled<true, 2>{L.b_1, w.F, w.h_plane, N_MODEL / 16};
+                ta.w2 = L.w_2; ta.w2_plane = (size_t)N_MODEL * N_MODEL;
+                ta.ln2 = EpiResLN<2, 4, 0>{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                ta.stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
+                EG_DBG(ta.trace = g_trace;)
+                if (int r = launch_tail(ta, rows, s)) return r;
+                if (last_dbg) return 0;
+                continue;
+            }
+        }
         if (!small_ln && !last_dbg) {
             // --- fused layer tail: fc+LN -> FFN-1 -> FFN-2+LN per 64-token block, two workgroups per CU (TM:92-93, 111-114, 135, 139)
             ProfScope ps(c, EGOEGO_K_FC_LN, s);

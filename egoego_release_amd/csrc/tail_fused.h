@@ -1,0 +1,274 @@
+// tail_fused.h — one decoder layer's tail (TM:92-93, 107-116, 135, 139) in ONE kernel for batches that do not fill the
+// chip with the 64-token workgroups of layer_tail_kernel (fewer than ~200 windows per GPU: every shard of the 8-GPU
+// split of BASELINE configs[2], configs[1]'s B = 64, the reference's own sample_bs = 1):
+//     fc (HD -> 512) + residual + LayerNorm  ->  FFN w_1 + ReLU  ->  FFN w_2 + residual + LayerNorm (+ padding mask)
+//
+// One 4-wave workgroup per block of 32*TT tokens (TT = 1, 2), one workgroup per CU: each wave owns a SIMD and 128 of the
+// 512 features for ALL tokens of the block, so every GEMM is one pass and a token's whole row is in the workgroup for
+// the LayerNorms.  Small batches are latency-bound (a lone workgroup's k-step through the LDS ring of gemm.h costs
+// 0.8 us whatever the occupancy, and a step is 11 dependent launches), so the operand fetch is built to run free:
+//   * WEIGHTS never touch LDS.  A wave's feature tiles are needed by no other wave, so its weight fragments go
+//     global -> VGPR through a buffer resource (SGPR base + SGPR offset + one VGPR holding 16*lane: the scalar unit
+//     does the address arithmetic), prefetched 3 k-steps ahead through a register ring: no LDS write, no LDS read,
+//     no workgroup barrier per k-step.
+//   * ACTIVATIONS stream global -> LDS (LDS-DMA) in chunks of 8 k-steps (128 columns), double-buffered: the next
+//     chunk is requested at the start of the current one and lands during its MFMAs; one barrier per chunk.  The
+//     three GEMMs read O (the attention output), the LayerNorm-1 output and the FFN hidden activations, the latter
+//     two written by this very workgroup moments earlier (they come back from L2).
+// The arithmetic is that of the large-batch kernels to the bit: the same MFMA order per output element (k ascending;
+// lo*hi, hi*lo, hi*hi) and the very same epilogue code (gemm.h EpiResLN / EpiTiled), so a window's numbers do not depend
+// on the batch it is sampled in (tests: batch-size and shard invariance).
+#pragma once
+#include "gemm.h"
+
+// perf-debug ablations of the k-loop (compile-time, results become wrong): 1 = no weight loads, 2 = no LDS fragment
+// reads, 4 = no LDS-DMA, 8 = no MFMAs
+#ifndef TAIL_ABLATE
+#define TAIL_ABLATE 0
+#endif
+
+struct TailArgs {
+    // fc + residual + LayerNorm (TM:92-93, 135)
+    const __bf16* o;         // attention output [Mp][HD], split-bf16 fragment-tiled (accumulator order along K)
+    size_t o_plane;          // elements between the hi and lo planes
+    int HD16;                // HD / 16
+    const __bf16* wfc;       // [512][HD] split-bf16 fragment-tiled, K permuted like o
+    size_t wfc_plane;
+    EpiResLN<2, 4, 0> ln1;   // bias, residual (layer input), gamma/beta, row mask, output hb (BT is a compile-time detail)
+    // FFN (TM:107-116, 139)
+    const __bf16* w1;
+    size_t w1_plane;
+    EpiTiled<true, 2> relu;  // bias, output f
+    const __bf16* w2;
+    size_t w2_plane;
+    EpiResLN<2, 4, 0> ln2;   // bias, residual hb, gamma/beta, row mask, output (+ optional int8 copy)
+    int stop;                // debug taps: 1 = return after LayerNorm-1, 2 = after FFN-1, 0 = run everything
+    EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][32] phase timestamps or nullptr
+};
+
+static constexpr int tail_smem_bytes(int TT) { return TT * 32 * 1024 + 3 * TT * 4 * 32 * TT * 4; }
+
+// Weight / activation fragments are fetched through buffer resources: address = SGPR base + SGPR offset + one VGPR
+// (plain global loads make hipcc build a 64-bit VGPR address per fragment and k-step: hundreds of registers of them).
+using tail_rsrc = __amdgpu_buffer_rsrc_t;
+EG_D tail_rsrc tail_make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
+EG_D i32x4 tail_load(tail_rsrc r, int voff, unsigned soff) {
+    return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// ---- one chunk of 8 k-steps -----------------------------------------------------------------------------------
+// acc += W[FT feature tiles][8 k-blocks at wcur] x act[TT token tiles][8 k-blocks of the LDS chunk buffer at `act`]
+// (layout [plane][t-tile][8 k-blocks][1 KiB], lo plane at +act_plane).  wq is the weight ring (RING slots, prefetch
+// distance PD = RING - 1): on entry the fragments of this chunk's k-steps 0 .. PD-1 are in it or in flight, with
+// nothing but younger weight loads issued after them; every k-step loads the fragments PD steps ahead — the next
+// chunk's first ones from wnext — unless LAST.  DP > 0: this wave's DP 1-KiB pieces of the next chunk are issued in
+// k-step 0 through dma(piece) (loads return in order: issued first, they have the whole chunk to land).
+// Activation fragments: the hi plane is double-buffered (read a k-step ahead), the lo plane is re-read right after the
+// one MFMA group that uses it; each fragment is consumed >= FT*TT MFMAs after its read was issued.
+template <int FT, int TT, int RING, bool LAST, int DP>
+struct TailChunk {
+    static constexpr int PD = RING - 1, NW = FT * 2;
+    static_assert(RING == 2 || RING == 4 || RING == 8, "ring slots must divide the 8 k-steps of a chunk");
+    static constexpr int n_ops(int s) { return ((s + PD < 8 || !LAST) ? NW : 0) + (s == 0 ? DP : 0); }
+    // vector-memory operations issued after the DMA pieces: what may stay in flight when the next chunk must have landed
+    static constexpr int after_dma() {
+        int n = 0;
+        for (int s = 1; s < 8; ++s) n += n_ops(s);
+        return n < 63 ? n : 63;
+    }
+    // vector-memory operations issued after the weight loads of k-step ks: what may still be in flight when they are needed
+    static constexpr int allowed(int ks) {
+        int n = 0;
+        if (ks < PD) {
+            n += (PD - 1 - ks) * NW;
+            for (int s = 0; s < ks; ++s) n += n_ops(s);
+        } else {
+            n += ks - PD == 0 ? DP : 0;
+            for (int s = ks - PD + 1; s < ks; ++s) n += n_ops(s);
+        }
+        return n < 63 ? n : 63;
+    }
+    static EG_D f32x16 mma(i32x4 w, i32x4 a, f32x16 c) {
+        if (TAIL_ABLATE & 8) return c;
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    }
+
+    template <int KS, class Dma>
+    static EG_D void step(f32x16 (&acc)[FT][TT], i32x4 (&wq)[RING][NW], i32x4 (&ah)[2][TT], i32x4 (&al)[TT], tail_rsrc wr,
+                          const unsigned (&wcur)[NW], const unsigned (&wnext)[NW], const char* act, int act_plane, int lane, Dma& dma) {
+        constexpr int cur = KS & 1;
+        // the weights and the hi-plane activations of this k-step have landed (counted: younger loads stay in flight)
+        asm volatile("" ::: "memory");
+        wait_counts<allowed(KS), (KS == 0 ? 0 : TT)>();
+        __builtin_amdgcn_sched_barrier(0);
+        if (KS + PD < 8 || !LAST) {
+            constexpr int kn = KS + PD;
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                if (!(TAIL_ABLATE & 1)) wq[kn % RING][q] = tail_load(wr, lane * 16, kn < 8 ? wcur[q] + (kn << 10) : wnext[q] + ((kn & 7) << 10));
+        }
+        if (KS == 0 && DP) {
+#pragma unroll
+            for (int d = 0; d < DP; ++d)
+                if (!(TAIL_ABLATE & 4)) dma(d);
+        }
+        if (KS < 7) {
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+                if (!(TAIL_ABLATE & 2)) ah[cur ^ 1][j] = *(const i32x4*)(act + ((j * 8 + KS + 1) << 10) + lane * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const i32x4(&w)[NW] = wq[KS % RING];
+        // part-major (two MFMAs on one accumulator are never back to back), in the order of gemm.h's mma_part:
+        // lo*hi, hi*lo, hi*hi.  w[2i] = hi plane of feature tile i, w[2i+1] = lo plane.
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i + 1], ah[cur][j], acc[i][j]);
+        asm volatile("" ::: "memory");
+        wait_counts<63, (KS < 7 ? TT : 0)>();  // the lo-plane activations of this k-step
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i], al[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (KS < 7) {
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+                if (!(TAIL_ABLATE & 2)) al[j] = *(const i32x4*)(act + act_plane + ((j * 8 + KS + 1) << 10) + lane * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i], ah[cur][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    template <class Dma>
+    static EG_D void run(f32x16 (&acc)[FT][TT], i32x4 (&wq)[RING][NW], tail_rsrc wr, const unsigned (&wcur)[NW],
+                         const unsigned (&wnext)[NW], const char* act, int act_plane, int lane, Dma dma) {
+        i32x4 ah[2][TT], al[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            ah[0][j] = *(const i32x4*)(act + ((j * 8) << 10) + lane * 16);
+            al[j] = *(const i32x4*)(act + act_plane + ((j * 8) << 10) + lane * 16);
+        }
+        step<0>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        step<1>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        step<2>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        step<3>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        step<4>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        step<5>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        step<6>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        step<7>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (DP) {  // the next chunk has landed; the weight prefetches issued after its pieces stay in flight
+            asm volatile("" ::: "memory");
+            wait_counts<after_dma(), 15>();
+        }
+    }
+};
+
+template <int TT>
+__global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
+    constexpr int TOK = 32 * TT, FT = 4, NW = 2 * FT, RING = 4, PD = RING - 1;
+    constexpr int CH_PLANE = TT * 8 * 1024, CH_BYTES = 2 * CH_PLANE;  // chunk buffer: [plane][t-tile][8 k-blocks][1 KiB]
+    constexpr int DMA_PIECES = 4 * TT;                                // 1-KiB pieces of a chunk per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const act = smem;
+    char* const red = smem + 2 * CH_BYTES;  // the LayerNorm epilogues' cross-wave reduction scratch
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63;
+    const int tok0 = (int)blockIdx.x * TOK;
+    const int tt0 = (int)blockIdx.x * TT;
+    EG_DBG(unsigned long long* const tr = a.trace ? a.trace + 180224 + (size_t)blockIdx.x * 32 : nullptr;)
+    auto mark = [&](int i) {
+        EG_DBG(if (tr && threadIdx.x == 0) {
+            tr[i] = wall_clock64();
+            tr[16 + i] = __builtin_readcyclecounter();  // shader clock ticks: clock = d(ticks) / d(wall)
+        })
+        (void)i;
+    };
+    mark(0);
+
+    f32x16 acc[FT][TT];
+    i32x4 wq[RING][NW];
+
+    // ---------------------------------------------------------------- GEMM: acc = in[tokens][K] x W[512][K]^T
+    auto w_offsets = [&](unsigned wplane_bytes, int K16, int kb, unsigned (&out)[NW]) {
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) out[2 * i + s] = s * wplane_bytes + (unsigned)(((wave * FT + i) * K16 + kb) << 10);
+    };
+    auto dma_piece = [&](tail_rsrc ir, unsigned iplane_bytes, int K16, int q, int piece) {
+        const int x = wave * DMA_PIECES + piece;  // flat index over [plane][t-tile][8 k-blocks]
+        const int s = x / (8 * TT), j = (x >> 3) % TT, kb = x & 7;
+        const unsigned src = s * iplane_bytes + (unsigned)(((tt0 + j) * K16 + 8 * q + kb) << 10);
+        char* dst = act + (q & 1) * CH_BYTES + s * CH_PLANE + ((j * 8 + kb) << 10);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ir, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, src, 0, 0);
+    };
+    auto gemm = [&](const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, int mark_id) {
+        const tail_rsrc wr = tail_make_rsrc(w), ir = tail_make_rsrc(in);
+        const unsigned wpb = (unsigned)(w_plane * 2), ipb = (unsigned)(in_plane * 2);
+        const int NQ = K16 / 8;
+        unsigned wcur[NW], wnext[NW];
+#pragma unroll
+        for (int pc = 0; pc < DMA_PIECES; ++pc) dma_piece(ir, ipb, K16, 0, pc);
+        w_offsets(wpb, K16, 0, wcur);
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+#pragma unroll
+            for (int q = 0; q < NW; ++q) wq[k][q] = tail_load(wr, lane * 16, wcur[q] + (k << 10));
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mark(mark_id);
+        for (int q = 0; q + 1 < NQ; ++q) {
+            w_offsets(wpb, K16, 8 * q, wcur);
+            w_offsets(wpb, K16, 8 * q + 8, wnext);
+            TailChunk<FT, TT, RING, false, DMA_PIECES>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
+                                                             [&](int piece) { dma_piece(ir, ipb, K16, q + 1, piece); });
+            // the next chunk has landed (counted wait inside run) and everyone is done with this one
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        w_offsets(wpb, K16, 8 * (NQ - 1), wcur);
+        TailChunk<FT, TT, RING, true, 0>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
+        __syncthreads();  // every wave is done with the chunk buffers (the epilogue's scratch sits behind them, but the next GEMM's first DMA does not)
+    };
+    // epilogue structs carry the large-batch kernels' code; only the tokens-per-block template argument differs
+    auto as_ln = [&](const EpiResLN<2, 4, 0>& e) {
+        return EpiResLN<2, 4, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale};
+    };
+
+    // =============================================================== 1. fc + residual + LayerNorm (TM:92-93, 135)
+    gemm(a.o, a.o_plane, a.HD16, a.wfc, a.wfc_plane, 7);
+    mark(1);
+    as_ln(a.ln1).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
+    // this workgroup's LayerNorm-1 rows must have reached L2 before its LDS-DMAs of them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    mark(2);
+    if (a.stop == 1) return;
+
+    // =============================================================== 2. FFN w_1 + ReLU (TM:111)
+    gemm(a.ln1.out, a.ln1.out_plane, 32, a.w1, a.w1_plane, 8);
+    mark(3);
+    a.relu.template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    mark(4);
+    if (a.stop == 2) return;
+
+    // =============================================================== 3. FFN w_2 + residual + LayerNorm (TM:111-114, 139)
+    gemm(a.relu.out, a.relu.out_plane, 32, a.w2, a.w2_plane, 9);
+    mark(5);
+    as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
+    EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
+    mark(6);
+}

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Phase timeline of the fused layer-tail kernel (perf-debug): main loop / epilogue of fc+LN, FFN-1, FFN-2+LN per workgroup."""
+"""Phase timeline of the fused layer-tail kernel (perf-debug build): per workgroup, wall-clock marks at
+ 0 start | 1 fc k-loops done | 2 LayerNorm-1 done | 3 FFN-1 k-loops | 4 FFN-1 epilogue | 5 FFN-2 k-loops | 6 LayerNorm-2 done.
+ (wall_clock64 ticks at 100 MHz)    TT_B=<batch> selects the batch size (and with it the token-block variant)."""
 import ctypes as C
 import os
 import sys
@@ -8,15 +10,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egoego_release_amd import ModelConfig, make_weights, _lib
-from egoego_release_amd import _lib as _eglib
-_eglib.use_perfdebug_build()  # needs `python -m egoego_release_amd.build --perfdebug`
+_lib.use_perfdebug_build()  # needs `python -m egoego_release_amd.build --perfdebug`
 from egoego_release_amd.model import CondGaussianDiffusion
 
-B, T = 256, 120
+B = int(os.environ.get("TT_B", 256))
+T = 120
 cfg = ModelConfig(max_timesteps=T + 1)
 m = CondGaussianDiffusion(**cfg.ctor_kwargs())
 m.load_state_dict(make_weights(cfg, 0), strict=False)
-m.hip_precision = int(os.environ.get("TT_PREC", _lib.PREC_I8X3))
 m = m.cuda()
 eng = m.hip_engine()
 lib = _lib.load()
@@ -28,14 +29,26 @@ torch.cuda.synchronize()
 buf = torch.zeros(262144, dtype=torch.int64, device="cuda")
 lib.egoego_debug_trace_buffer.argtypes = [C.c_void_p]
 lib.egoego_debug_trace_buffer(C.c_void_p(buf.data_ptr()))
-eng.debug_stage(x, xc, t, 1, "embed") if False else eng.denoise(x, xc, t)
+eng.denoise(x, xc, t)
 torch.cuda.synchronize()
 lib.egoego_debug_trace_buffer(None)
-raw = buf.cpu()
-nb = B * 128 // 64
-ph = [raw[p * 4096:p * 4096 + nb * 4].view(nb, 4)[:, :3].double() / 100.0 for p in range(3)]
-t0 = ph[0][:, 0].min()
-print("kernel span %.1f us" % (ph[2][:, 2].max() - t0))
-for name, a in zip(("fc + LN", "FFN-1", "FFN-2 + LN"), ph):
-    print(f"{name:11s} main loop {(a[:, 1] - a[:, 0]).mean():7.2f} us   epilogue {(a[:, 2] - a[:, 1]).mean():7.2f} us")
-print("gap fc->FFN-1 %.2f us, FFN-1->FFN-2 %.2f us" % ((ph[1][:, 0] - ph[0][:, 2]).mean(), (ph[2][:, 0] - ph[1][:, 2]).mean()))
+nwg = {True: B * 128 // 128}.get(True)
+tr = buf.cpu().numpy()[180224:180224 + 32768].reshape(-1, 32)
+tr = tr[(tr[:, 0] > 0) & (tr[:, 6] > 0)]
+print("workgroups traced:", len(tr))
+t0 = tr[:, 0].min()
+names = {1: "fc k-loops", 2: "LayerNorm-1", 3: "FFN-1 k-loops", 4: "FFN-1 epilogue", 5: "FFN-2 k-loops", 6: "LayerNorm-2"}
+prev = 0
+for i in range(1, 7):
+    if (tr[:, i] == 0).all():
+        continue
+    d = (tr[:, i] - tr[:, prev]) / 100.0
+    mhz = ((tr[:, 16 + i] - tr[:, 16 + prev]) / d).mean()
+    print(f"{names[i]:18s} mean {d.mean():7.2f} us   min {d.min():7.2f}   max {d.max():7.2f}   shader clock {mhz:6.0f} MHz")
+    prev = i
+for nm, (pro, st, en) in {"fc": (0, 7, 1), "FFN-1": (2, 8, 3), "FFN-2": (4, 9, 5)}.items():
+    print(f"{nm:6s} prologue (first chunk + weights + residual in flight -> landed) {((tr[:, st] - tr[:, pro]) / 100.0).mean():6.2f} us,"
+          f" chunk loop {((tr[:, en] - tr[:, st]) / 100.0).mean():6.2f} us at {((tr[:, 16 + en] - tr[:, 16 + st]) / ((tr[:, en] - tr[:, st]) / 100.0)).mean():5.0f} MHz")
+tot = (tr[:, 6] - tr[:, 0]) / 100.0
+print(f"workgroup total     mean {tot.mean():7.2f} us   min {tot.min():7.2f}   max {tot.max():7.2f}")
+print(f"kernel span {(tr[:, 6].max() - t0) / 100.0:.2f} us; start spread {(tr[:, 0].max() - t0) / 100.0:.2f} us")
