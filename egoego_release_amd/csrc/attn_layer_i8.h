@@ -341,3 +341,51 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
         mark(8);
     })
 }
+
+// ---- Q/K/V projections on int8 slices for windows the fused kernel above does not cover (T + 1 <= 64 or > 128) ----------
+// The same int8 main loop and dequantisation, one 256-feature x 128-token block per workgroup, handing fp32 tiles to the
+// split-bf16 epilogues of gemm.h (EpiQK / EpiV): Q, K, V go to memory in attention.h's operand layouts and attn_kernel
+// runs the attention core.  Feature blocks 0 .. n_qk-1 are Q/K (swapped accumulator), the rest V (un-swapped).
+struct QkvI8Args {
+    const int8_t* w8;      // [3*HD][512] two slices
+    size_t w_plane;        // bytes between slices
+    const float* w_scale;  // [3*HD]
+    const int8_t* h8;      // [Mp][512] two slices
+    size_t h_plane;
+    const float* h_scale;  // [Mp]
+    int ntb, n_qk;         // token blocks in the grid; number of Q/K feature blocks
+};
+
+template <class EQK, class EV>
+__global__ __launch_bounds__(256, 1) void qkv_i8_kernel(QkvI8Args a, EQK eqk, EV ev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int fblk, tblk;
+    grouped_map(lid, (int)gridDim.x / a.ntb, a.ntb, fblk, tblk);
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const int wf = wave & 1, wt = wave >> 1;
+    const int f0 = fblk * 256 + wf * 128, t0 = tblk * 128 + wt * 64;
+    const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
+    I8Acc q[4][2];
+    f32x16 v[4][2];
+    if (fblk < a.n_qk) {
+        GemmBody<AL8K, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float sa = a.h_scale[t0 + j * 32 + col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) i8_dequant(q[i][j], v[i][j], a.w_scale + f0 + i * 32 + 4 * hf, sa);
+        }
+        eqk.template run<4, 2>(v, f0, t0, lane, wf, wt, smem);
+    } else {
+        GemmBody<AL8V, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sw = a.w_scale[f0 + i * 32 + col];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) i8_dequant_rows(q[i][j], v[i][j], sw, a.h_scale + t0 + j * 32 + 4 * hf);
+        }
+        ev.template run<4, 2>(v, f0, t0, lane, wf, wt, smem);
+    }
+}

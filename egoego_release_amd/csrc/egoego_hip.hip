@@ -321,7 +321,7 @@ static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
     return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
 }
 
-// Fused small-batch tail (tail_fused.h): 64-token workgroups while they fill the CUs at least once, 32-token ones below.
+// Fused small-batch tail (tail_fused.h): 64-token workgroups when they fill the CUs exactly once, 32-token ones below.
 static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
     static bool once = false;
     if (!once) {
@@ -360,7 +360,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     // i8x3: windows of 97..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
     // layer reads the embed output as int8 rows
-    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3 && g.KT == 4 && g.Lp == BLK_A_T;
+    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;  // every layer input also as int8 rows
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
         if (i8_path) {
@@ -387,8 +387,8 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         const bool i8 = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;
         const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && (i8 || nw * H >= 192);
         const bool fused_attn = attn_geom && !dbg_qkv;
-        // the layer's output also as int8 slices when the next layer's attention kernel consumes them
-        const bool q8_out = i8 && attn_geom && li + 1 < c->cfg.n_dec_layers;
+        // the layer's output also as int8 slices: the next layer's projections consume them
+        const bool q8_out = i8 && li + 1 < c->cfg.n_dec_layers;
         int8_t* const q8p = q8_out ? w.hA8 : nullptr;
         if (fused_attn && i8) {
             ProfScope ps(c, EGOEGO_K_QKV, s);
@@ -416,7 +416,19 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             HIP_TRY(hipGetLastError());
         } else {
             // --- Q, K, V projections (TM:71-73)
-            {
+            if (i8 && !dbg_qkv) {
+                // int8-slice projections feeding the split-bf16 attention core (windows outside the fused kernel's range)
+                ProfScope ps(c, EGOEGO_K_QKV, s);
+                QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, tb_a, 2 * HD / BLK_A_F};
+                auto kern = qkv_i8_kernel<EpiQK<NP>, EpiV<NP>>;
+                static bool once = false;
+                if (!once) {
+                    HIP_TRY(allow_smem(kern, AL8K::SMEM_BYTES));
+                    once = true;
+                }
+                kern<<<dim3((3 * HD / BLK_A_F) * tb_a), dim3(256), AL8K::SMEM_BYTES, s>>>(qa, eqk, ev);
+                HIP_TRY(hipGetLastError());
+            } else {
                 ProfScope ps(c, EGOEGO_K_QKV, s);
                 GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
                 auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;

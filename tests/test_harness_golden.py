@@ -257,3 +257,51 @@ def test_demo_trajectory_through_gpu_harness(hg):
     assert _angle(aa[0, :, 1:], aa[1, :, 1:]).max() < 1e-3
     rot0 = Rot.from_quat(np.array([[0.0, 0.0, np.sin(0.55), np.cos(0.55)]])) * Rot.from_rotvec(aa[0, :, 0].astype(np.float64))
     assert np.abs((rot0 * Rot.from_rotvec(aa[1, :, 0].astype(np.float64)).inv()).magnitude()).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ entry point
+def test_mpjpe_matches_the_reference_definition():
+    """kinpoly/scripts/eval_metrics_imu_rec.py:297-301: root-relative, mean over frames and joints, millimetres."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("run_stage2_demo", os.path.join(ROOT, "tools", "run_stage2_demo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.random.default_rng(0)
+    gt = g.standard_normal((7, 22, 3))
+    pred = gt + np.array([0.3, -0.2, 0.1])            # a pure root offset costs nothing
+    assert mod.mpjpe_mm(pred, gt) < 1e-9
+    pred = gt.copy()
+    pred[:, 5] += np.array([0.003, 0.0, 0.004])       # one joint off by 5 mm -> 5/22 mm on average
+    assert abs(mod.mpjpe_mm(pred, gt) - 5.0 / 22) < 1e-9
+    want = np.linalg.norm((pred - pred[:, 0:1]) - (gt - gt[:, 0:1]), axis=2).mean() * 1000
+    assert abs(mod.mpjpe_mm(pred, gt) - want) < 1e-12
+
+
+@pytest.mark.gpu
+def test_stage2_entry_point_on_the_demo_trajectory(hg, tmp_path):
+    """tools/run_stage2_demo.py with the reference's --diffusion_* flags on the 140-frame demo head trajectory, the real
+    statistics and synthetic weights: two windows (120 + 30 frames), finite outputs of the reference's shapes, an MPJPE
+    against the demo's own FK joints, and the same numbers as calling the harness directly."""
+    import importlib.util
+    import pickle
+    spec = importlib.util.spec_from_file_location("run_stage2_demo", os.path.join(ROOT, "tools", "run_stage2_demo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ds, dso = _stats(hg)
+    np.save(tmp_path / "head.npy", hg["demo_head_qpos"])
+    np.save(tmp_path / "rest.npy", REST_OFFSETS)
+    with open(tmp_path / "stats.p", "wb") as f:
+        pickle.dump({"global_jpos_min": hg["stats_global_jpos_min"], "global_jpos_max": hg["stats_global_jpos_max"]}, f)
+    aa_gt = np.concatenate([hg["demo_root_orient"][:, None], hg["demo_body_pose"].reshape(-1, 21, 3)], 1)
+    _, gj = dso.fk(hg["demo_trans"], aa_gt)
+    np.save(tmp_path / "gt.npy", gj)
+    argv = ["--head_pose", str(tmp_path / "head.npy"), "--stats", str(tmp_path / "stats.p"), "--rest_offsets", str(tmp_path / "rest.npy"),
+            "--gt_jpos", str(tmp_path / "gt.npy"), "--diffusion_window", "120", "--diffusion_batch_size", "2", "--timesteps", "5",
+            "--sampling_rng", "philox", "--seed", "3", "--out", str(tmp_path / "out.npz"), "--use_min_max", "--canonicalize_init_head"]
+    rep = mod.main(argv)
+    assert rep["frames"] == 140 and rep["samples"] == 2 and rep["windows"] == 2 and len(rep["mpjpe_mm"]) == 2
+    out = np.load(tmp_path / "out.npz")
+    assert out["local_aa"].shape == (2, 140, 22, 3) and out["root_trans"].shape == (2, 140, 3) and out["global_jpos"].shape == (2, 140, 22, 3)
+    assert all(np.isfinite(out[k]).all() for k in out.files) and all(np.isfinite(v) and v > 0 for v in rep["mpjpe_mm"])
+    # the two samples share the head trajectory and (Philox keyed by window index) differ in their noise
+    assert not np.array_equal(out["local_aa"][0], out["local_aa"][1])
