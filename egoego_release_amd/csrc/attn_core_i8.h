@@ -1,0 +1,339 @@
+// attn_core_i8.h — the attention front end on int8 slices for windows the one-kernel form (attn_layer_i8.h, <= 128 tokens)
+// cannot hold on chip: up to 224 tokens (BASELINE configs[3]: T = 196).  Two kernels per layer:
+//
+//   qkv_i8q_kernel       Q/K/V projections (TM:71-73) on int8 slices, one 256-feature (= one head of Q, K or V) x 128-token
+//                        block per workgroup, results QUANTISED in the epilogue and written as the int8 operand images
+//                        of the core kernel: Q and K per row (query / key) with one scale each, V transposed with one
+//                        scale per key.  2 bytes per value go to memory instead of the 4 of the split-bf16 form — at
+//                        T = 196 the Q/K/V round trip (0.7 GB written, 1.2 GB read per layer at B = 256) is what bounds
+//                        the split-bf16 pair.
+//   attn_core_i8_kernel  one 4-wave workgroup per (window, head, block of 4 query tiles): the head's K image
+//                        (<= 112 KiB) comes into LDS by LDS-DMA, S^T = K Q^T on int8 MFMAs with the queries' Q
+//                        fragments in registers, softmax in-lane (TM:76-82), P * (V's key scales) quantised per query
+//                        into registers, the V^T image over the K image, O^T = V^T P, 1/rowsum, split-bf16 store.
+//
+// Scales.  K, Q: one per row (maximum over the 256 d_k of the head).  V: one per KEY row (maximum over the 256 d_v);
+// it multiplies the probabilities before they are quantised, so that the PV contraction over all keys of the window is
+// ONE integer accumulation: O[q,d] = (1/sum_q) sum_k (p[q,k] s_v[k]) vq[k,d].  (The one-kernel form scales V per feature
+// column over the window's keys; here a 128-token block may straddle two windows.)
+// Fragment orders are those of attn_layer_i8.h: every operand produced by an accumulator is 16 consecutive bytes per
+// lane and tile ("acc32" order), both operands of a product permuted alike.
+#pragma once
+#include "attn_layer_i8.h"
+
+struct Qkv8Out {
+    int8_t *q8, *k8, *v8;  // [B*H][KT][8][1 KiB] (Q, K: token tile, d_k block) / [B*H][8][KT][1 KiB] (V^T: d_v tile, key block); slice 2 at +plane
+    size_t plane;          // bytes between the two slices of each tensor
+    float *sq, *sk, *sv;   // [B*H][Lp] row scales
+    const float* bias;     // [3*HD]
+    float qscale;          // 1 / sqrt(d_k)
+    int Lp, KT, H, HD, Mvalid;
+};
+
+// Quantise 16 values, each with its own inverse scale, into the two slices (cf. common.h quant16).
+EG_D void quant16v(const float v[16], const float inv[16], u32x4& s1, u32x4& s2) {
+    uint32_t u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[i], inv[i], 12582912.0f));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t a = u[4 * w], b = u[4 * w + 1], c = u[4 * w + 2], d = u[4 * w + 3];
+        s2[w] = __builtin_amdgcn_perm(b, a, 0x0c0c0400u) | __builtin_amdgcn_perm(d, c, 0x04000c0cu);
+        const uint32_t a1 = a + 128u, b1 = b + 128u, c1 = c + 128u, d1 = d + 128u;
+        s1[w] = __builtin_amdgcn_perm(b1, a1, 0x0c0c0501u) | __builtin_amdgcn_perm(d1, c1, 0x05010c0cu);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int fblk, tblk;
+    grouped_map(lid, (int)gridDim.x / a.ntb, a.ntb, fblk, tblk);
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const int wf = wave & 1, wt = wave >> 1;
+    const int f0 = fblk * 256 + wf * 128, t0 = tblk * 128 + wt * 64;
+    const int which = fblk * 256 / o.HD, h = (fblk * 256 % o.HD) >> 8;  // 0 = Q, 1 = K, 2 = V; head
+    const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
+    float* red = (float*)smem;  // [2][128] cross-wave maxima; the main loop's ring is dead when it is used
+    I8Acc q[4][2];
+    f32x16 v[4][2];
+    if (which < 2) {
+        // ---- Q_h / K_h: lane owns a token; one scale per row; int8 image [token tile][d_k block]
+        GemmBody<AL8K, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        const float sc = which == 0 ? o.qscale : 1.0f;
+        float amax[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float sa = a.h_scale[t0 + j * 32 + col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                i8_dequant(q[i][j], v[i][j], a.w_scale + f0 + i * 32 + 4 * hf, sa);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 b4 = *(const float4*)(o.bias + f0 + i * 32 + 8 * gq + 4 * hf);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        v[i][j][4 * gq + c] = (v[i][j][4 * gq + c] + bb[c]) * sc;
+                        amax[j] = fmaxf(amax[j], fabsf(v[i][j][4 * gq + c]));
+                    }
+                }
+            }
+            amax[j] = fmaxf(amax[j], __shfl_xor(amax[j], 32));
+            if (hf == 0) red[wf * 128 + wt * 64 + j * 32 + col] = amax[j];
+        }
+        __syncthreads();
+        int8_t* dst8 = which == 0 ? o.q8 : o.k8;
+        float* dsts = which == 0 ? o.sq : o.sk;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m0 = t0 + j * 32;
+            if (m0 >= o.Mvalid) continue;
+            const int b = m0 / o.Lp, lt = (m0 % o.Lp) >> 5, bh = b * o.H + h;
+            const int tokb = wt * 64 + j * 32 + col;
+            const float rmax = fmaxf(red[tokb], red[128 + tokb]);
+            const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+            if (wf == 0 && hf == 0) dsts[(size_t)bh * o.Lp + lt * 32 + col] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
+                u32x4 s1, s2;
+                quant16(t, inv, s1, s2);
+                int8_t* p = dst8 + ((((size_t)bh * o.KT + lt) * 8 + wf * 4 + i) << 10) + lane * 16;
+                *(u32x4*)p = s1;
+                *(u32x4*)(p + o.plane) = s2;
+            }
+        }
+    } else {
+        // ---- V_h: un-swapped accumulator (lane owns a feature, registers walk the tokens); one scale per KEY row
+        // (maximum over the head's 256 features: four tiles in-lane, 32 lanes by shuffles, two waves through LDS);
+        // stored transposed [d_v tile][key block]
+        GemmBody<AL8V, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        float tmax[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax[j][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sw = a.w_scale[f0 + i * 32 + col], bf = o.bias[f0 + i * 32 + col];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                i8_dequant_rows(q[i][j], v[i][j], sw, a.h_scale + t0 + j * 32 + 4 * hf);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[i][j][r] += bf;
+                    tmax[j][r] = fmaxf(tmax[j][r], fabsf(v[i][j][r]));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m = tmax[j][r];
+#pragma unroll
+                for (int s = 1; s < 32; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
+                tmax[j][r] = m;
+                // token of register r: 8 (r >> 2) + 4 hf + (r & 3) within tile j
+                if (col == 0) red[wf * 128 + wt * 64 + j * 32 + mfma32_row(r, hf)] = m;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m0 = t0 + j * 32;
+            if (m0 >= o.Mvalid) continue;
+            const int b = m0 / o.Lp, lt = (m0 % o.Lp) >> 5, bh = b * o.H + h;
+            float inv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tokb = wt * 64 + j * 32 + mfma32_row(r, hf);
+                const float rmax = fmaxf(red[tokb], red[128 + tokb]);
+                inv[r] = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+                if (wf == 0 && col == 0) o.sv[(size_t)bh * o.Lp + lt * 32 + mfma32_row(r, hf)] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
+                u32x4 s1, s2;
+                quant16v(t, inv, s1, s2);
+                int8_t* p = o.v8 + ((((size_t)bh * 8 + wf * 4 + i) * o.KT + lt) << 10) + lane * 16;
+                *(u32x4*)p = s1;
+                *(u32x4*)(p + o.plane) = s2;
+            }
+        }
+    }
+}
+
+struct AttnCore8Args {
+    const int8_t *q8, *k8, *v8;
+    size_t plane;
+    const float *sq, *sk, *sv;
+    __bf16* o;  // [Mp][HD] split-bf16 fragment-tiled (accumulator order): the fc GEMM's operand
+    size_t o_plane;
+    int HD16, H, L, Lp;
+};
+
+template <int KT>
+__global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
+    constexpr int IMG = KT * 8 * 1024;  // bytes of one slice of the K (or V^T) image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* kv = smem;                           // [slice][...]
+    float* sk = (float*)(smem + 2 * IMG);      // [KT*32] key scales of K
+    float* sv = sk + KT * 32;                  // [KT*32] key scales of V
+    const int bh = (int)blockIdx.y, qb = (int)blockIdx.x;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const int qt_raw = qb * 4 + wave;
+    const bool active = qt_raw < KT;
+    const int qt = active ? qt_raw : KT - 1;
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)a.k8, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)a.v8, 0, 0x7fffffff, 0x00020000);
+    // ---- K image -> LDS (LDS-DMA, KT*16 pieces of 1 KiB over the four waves); Q fragments and scales -> registers
+    auto dma_image = [&](__amdgpu_buffer_rsrc_t r) {
+        for (int pc = wave; pc < KT * 16; pc += 4) {
+            const int s = pc / (KT * 8), blk = pc - s * KT * 8;
+            const unsigned src = (unsigned)(s * a.plane) + (unsigned)(((size_t)bh * KT * 8 + blk) << 10);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kv + s * IMG + (blk << 10)), 16, lane * 16, src, 0, 0);
+        }
+    };
+    dma_image(kr);
+    for (int i = threadIdx.x; i < KT * 32; i += 256) {
+        sk[i] = a.sk[(size_t)bh * a.Lp + i];
+        sv[i] = a.sv[(size_t)bh * a.Lp + i];
+    }
+    i32x4 qs1[8], qs2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int8_t* p = a.q8 + ((((size_t)bh * KT + qt) * 8 + i) << 10) + lane * 16;
+        qs1[i] = *(const i32x4*)p;
+        qs2[i] = *(const i32x4*)(p + a.plane);
+    }
+    const float sq = a.sq[(size_t)bh * a.Lp + qt * 32 + col];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- S^T = K Q^T, softmax over keys (TM:76-82), P * s_v quantised per query
+    i32x4 ps1[KT], ps2[KT];
+    float oscale;
+    {
+        I8Acc s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc_zero(s[kt]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            i32x4 k1[KT], k2[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const char* src = kv + ((kt * 8 + i) << 10) + lane * 16;
+                k1[kt] = lds_frag(src);
+                k2[kt] = lds_frag(src + IMG);
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k2[kt], qs1[i], s[kt].m, 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs2[i], s[kt].m, 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs1[i], s[kt].h, 0, 0, 0);
+        }
+        float p[KT][16];
+        float mx = -INFINITY;
+        const float sq256 = sq * 256.0f * 1.44269504088896f;  // logits in units of log2(e): softmax through v_exp_f32
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 k4 = *(const float4*)(sk + kt * 32 + 8 * gq + 4 * hf);
+                const float ks[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = 4 * gq + c;
+                    float val = (float)i8_combine(s[kt].h[r], s[kt].m[r]) * (sq256 * ks[c]);
+                    if (kt * 32 + 8 * gq + 4 * hf + c >= a.L) val = -INFINITY;
+                    p[kt][r] = val;
+                    mx = fmaxf(mx, val);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f, pmax = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 v4 = *(const float4*)(sv + kt * 32 + 8 * gq + 4 * hf);
+                const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = 4 * gq + c;
+                    const float e = __builtin_amdgcn_exp2f(p[kt][r] - mx);
+                    sum += e;
+                    p[kt][r] = e * vs[c];  // the key's V scale rides on the probability
+                    pmax = fmaxf(pmax, p[kt][r]);
+                }
+            }
+        sum += __shfl_xor(sum, 32);
+        pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
+        const float pinv = pmax > 0.f ? I8_QMAX / pmax : 0.f;
+        oscale = (1.0f / sum) * (pmax > 0.f ? pmax / I8_QMAX : 0.f) * 256.0f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            u32x4 s1, s2;
+            quant16(p[kt], pinv, s1, s2);
+            ps1[kt] = __builtin_bit_cast(i32x4, s1);
+            ps2[kt] = __builtin_bit_cast(i32x4, s2);
+        }
+    }
+    // ---- V^T image over the K image (every wave is done with K)
+    __syncthreads();
+    dma_image(vr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- O^T = V^T P (TM:83-88), heads merged on store
+    const int m = b * a.Lp + qt * 32 + col;
+#pragma unroll 1
+    for (int dvh = 0; dvh < 2; ++dvh) {
+        I8Acc o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc_zero(o[dt]);
+#pragma unroll
+        for (int kb = 0; kb < KT; ++kb) {
+            i32x4 v1[4], v2[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* src = kv + (((dvh * 4 + dt) * KT + kb) << 10) + lane * 16;
+                v1[dt] = lds_frag(src);
+                v2[dt] = lds_frag(src + IMG);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], ps1[kb], o[dt].m, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps2[kb], o[dt].m, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps1[kb], o[dt].h, 0, 0, 0);
+        }
+        if (active) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int tile = dvh * 4 + dt;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (float)i8_combine(o[dt].h[8 * jj + e], o[dt].m[8 * jj + e]) * oscale;
+                    u32x4 hi, lo;
+                    split8(t, hi, lo);
+                    const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
+                    *(u32x4*)(a.o + idx) = hi;
+                    *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                }
+            }
+        }
+    }
+}

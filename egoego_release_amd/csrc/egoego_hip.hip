@@ -13,6 +13,7 @@
 
 #include "attention.h"
 #include "attn_layer_i8.h"
+#include "attn_core_i8.h"
 #include "common.h"
 #include "gemm.h"
 #include "pointwise.h"
@@ -124,6 +125,7 @@ struct Workspace {
     size_t xall_plane, h_plane, qkv_plane, o_plane;
     int8_t* hA8;      // int8 slices of hA (i8x3 consumers), slice stride h_plane bytes
     float* hA_scale;  // [Mp]
+    float *sq8, *sk8, *sv8;  // [B*H][Lp] row scales of the int8 Q / K / V images (attn_core_i8.h; the images alias Q, K, V)
     size_t total;
 };
 
@@ -153,6 +155,9 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
     w.O = (__bf16*)take(2 * w.o_plane * 2);
     w.hA8 = (int8_t*)take(2 * w.h_plane);
     w.hA_scale = (float*)take(sizeof(float) * g.Mp);
+    w.sq8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
+    w.sk8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
+    w.sv8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
     w.total = off;
 }
 
@@ -337,6 +342,29 @@ static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
     return 0;
 }
 
+template <int KT>
+static int launch_attn_core8_kt(const AttnCore8Args& a, int BH, hipStream_t s) {
+    auto kern = attn_core_i8_kernel<KT>;
+    constexpr int smem = 2 * KT * 8 * 1024 + 2 * KT * 32 * 4;
+    static bool once = false;
+    if (!once) {
+        HIP_TRY(allow_smem(kern, smem));
+        once = true;
+    }
+    kern<<<dim3((KT + 3) / 4, BH), dim3(256), smem, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static int launch_attn_core8(const AttnCore8Args& a, int KT, int BH, hipStream_t s) {
+    switch (KT) {
+        case 1: return launch_attn_core8_kt<1>(a, BH, s);
+        case 2: return launch_attn_core8_kt<2>(a, BH, s);
+        case 4: return launch_attn_core8_kt<4>(a, BH, s);
+        case 7: return launch_attn_core8_kt<7>(a, BH, s);
+    }
+    return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
+}
+
 // ------------------------------------------------------------------------------------ the step
 struct StepIO {
     const float* row_mask;  // packed [Mp] or nullptr
@@ -416,8 +444,31 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             HIP_TRY(hipGetLastError());
         } else {
             // --- Q, K, V projections (TM:71-73)
-            if (i8 && !dbg_qkv) {
-                // int8-slice projections feeding the split-bf16 attention core (windows outside the fused kernel's range)
+            const bool core8 = i8 && !dbg_qkv && g.KT == 7;  // long windows: int8 operand images + int8 attention core
+            if (core8) {
+                // int8-slice projections written as int8 operand images + the int8 attention core (attn_core_i8.h): windows
+                // outside the one-kernel form's range
+                {
+                    ProfScope ps(c, EGOEGO_K_QKV, s);
+                    QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, tb_a, 2 * HD / BLK_A_F};
+                    Qkv8Out qo{(int8_t*)w.Q, (int8_t*)w.K, (int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, L.b_qkv,
+                               1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid};
+                    static bool once = false;
+                    if (!once) {
+                        HIP_TRY(allow_smem(qkv_i8q_kernel, AL8K::SMEM_BYTES));
+                        once = true;
+                    }
+                    qkv_i8q_kernel<<<dim3((3 * HD / BLK_A_F) * tb_a), dim3(256), AL8K::SMEM_BYTES, s>>>(qa, qo);
+                    HIP_TRY(hipGetLastError());
+                }
+                {
+                    ProfScope ps(c, EGOEGO_K_ATTN, s);
+                    AttnCore8Args ca{(const int8_t*)w.Q, (const int8_t*)w.K, (const int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, w.O, w.o_plane,
+                                     HD / 16, H, g.L, g.Lp};
+                    if (int r = launch_attn_core8(ca, g.KT, g.B * H, s)) return r;
+                }
+            } else if (i8 && !dbg_qkv) {
+                // short windows: int8-slice projections feeding the split-bf16 attention core
                 ProfScope ps(c, EGOEGO_K_QKV, s);
                 QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, tb_a, 2 * HD / BLK_A_F};
                 auto kern = qkv_i8_kernel<EpiQK<NP>, EpiV<NP>>;
@@ -442,7 +493,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             }
             if (dbg_qkv) return 0;
             // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
-            {
+            if (!core8) {
                 ProfScope ps(c, EGOEGO_K_ATTN, s);
                 if (int r = launch_attn<NP>(aa, g.KT, nw * H, s)) return r;
             }
