@@ -201,17 +201,20 @@ def main():
         steps_per_s = K / el
         fl_step = flops_per_window_step(T) * B
         i8 = args.precision == 8 and 64 < T + 1 <= 128
-        attn_name = "attn_layer_i8_kernel" if i8 else "qkv_attn_kernel"
-        attn_peak = PEAK_I8_TOPS if i8 else PEAK_BF16_TFLOPS
-        attn_ach = qkv_attn_flops_per_launch(Bl, T) / (k_us * 1e-6) / 1e12 if k_n else None
+        i8_long = args.precision == 8 and T + 1 > 128   # int8 projections written as int8 images + separate int8 attention core
+        attn_name = "attn_layer_i8_kernel" if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
+        attn_peak = PEAK_I8_TOPS if (i8 or i8_long) else PEAK_BF16_TFLOPS
+        attn_flops = Bl * 2 * (T + 1) * 512 * 3 * 1024 if i8_long else qkv_attn_flops_per_launch(Bl, T)
+        attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None
         tail_ach = tail_flops_per_launch(Bl, T) / (t_us * 1e-6) / 1e12 if t_n else None
         L = T + 1
         ms_step = 1e3 * el / K
         attn_roof = {
             "bound": "mfma", "kernel": attn_name + (" (Q/K/V projections, softmax and PV of one window x head per workgroup, int8 slices; "
                                                     "K, V and the probabilities stay in LDS/registers)" if i8 else
-                                                    " (fused Q/K/V projection + attention, split-bf16)"),
-            "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if i8 else "TFLOP/s",
+                                                    (" (Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8_kernel; "
+                                                     "projection operations only)" if i8_long else " (fused Q/K/V projection + attention, split-bf16)")),
+            "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if (i8 or i8_long) else "TFLOP/s",
             "frac": (attn_ach / attn_peak) if attn_ach else None,
             "traffic": (traffic.get(attn_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
             "algorithmic_bytes": (2 * Bl * L * 512 + 4 * Bl * L * 1024 + 3 * 2 * 512 * 1024) if i8 else (4 * Bl * L * (512 + 1024) + 6.3e6),
@@ -219,10 +222,14 @@ def main():
             "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time, measured on rank 0's shard right after "
                     "the timed region; three MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe "
                     "utilisation is 3x this fraction"}
+        tail_name = "layer_tail_kernel" if Bl * (T + 1 + 31) // 32 * 32 // 128 > 128 and Bl >= 200 else "tail_kernel"
         tail_roof = {
-            "bound": "mfma", "kernel": "layer_tail_kernel (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, split-bf16)",
+            "bound": "mfma", "kernel": tail_name + (" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, two workgroups per CU, "
+                                                    "LDS-ring operands, split-bf16)" if tail_name == "layer_tail_kernel" else
+                                                    " (the same three GEMMs per 32/64 tokens for small batches: weights streamed into registers, "
+                                                    "activations by LDS-DMA chunks, split-bf16)"),
             "achieved": tail_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (tail_ach / PEAK_BF16_TFLOPS) if tail_ach else None,
-            "traffic": (traffic.get("layer_tail_kernel") or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
+            "traffic": (traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
             "algorithmic_bytes": 4 * Bl * L * (1024 + 512 + 512) + 4.2e6,
             "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * ms_step) if t_n else None,
             "note": "measured like the attention-layer kernel; split-bf16 issues 3 MFMAs per product (pipe utilisation 3x)"}

@@ -19,8 +19,8 @@ ALG = {  # kernel tag -> (what, algorithmic FLOPs per launch, algorithmic HBM by
 
 
 def main():
-    stats = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_b256_t120_kernel_stats.csv"))))
-    traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+    stats = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_b256_t120_kernel_stats.csv"))))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["kernels"]
     rows = []
     for tag, (what, flops, abytes) in ALG.items():
         st = next(r for r in stats if tag in r["Name"])
@@ -30,7 +30,7 @@ def main():
         peak = PEAK_I8 if "i8" in tag else PEAK_TF
         rows.append((tag, what, us, float(st["Percentage"]), flops / us / 1e6, flops / us / 1e6 / peak, 3 * flops / us / 1e6 / peak,
                      abytes / 1e6, (hbm or 0) / 1e6, (hbm or 0) / us / 1e6))
-    out = ["# Per-kernel roofline, round 1 (B=256, T=120, precision i8x3: int8-slice attention layer + split-bf16 elsewhere; from the files in this directory)", "",
+    out = ["# Per-kernel roofline, round 2 (B=256, T=120, precision i8x3: int8-slice attention layer + split-bf16 elsewhere; from the files in this directory)", "",
            "MFMA bound: 2.5 PFLOP/s dense bf16, 5 POP/s dense int8; both split-bf16 and the int8 slices issue 3 MFMAs per algorithmic product, so the algorithmic fraction is capped at 33 %.",
            "HBM bound: 8 TB/s.  `traffic` = (2·FETCH_SIZE + WRITE_SIZE)·1024 from the PMC passes.", "",
            "| kernel | what | avg µs | % of GPU time | algorithmic TFLOP/s (TOP/s) | frac of the dtype's peak | MFMA-pipe frac (×3) | algorithmic MB | measured HBM MB | HBM TB/s |",
@@ -38,7 +38,7 @@ def main():
     for r in rows:
         out.append(f"| `{r[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.1f} | {r[4]:.0f} | {r[5]:.3f} | {r[6]:.3f} | {r[7]:.0f} | {r[8]:.0f} | {r[9]:.2f} |")
     text = "\n".join(out) + "\n"
-    open(os.path.join(ROOT, "profiles", "r01_roofline.md"), "w").write(text)
+    open(os.path.join(ROOT, "profiles", "r02_roofline.md"), "w").write(text)
     sys.stdout.write(text)
 
 
