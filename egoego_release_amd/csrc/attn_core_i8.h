@@ -1,8 +1,8 @@
 // attn_core_i8.h — the attention front end on int8 slices for windows the one-kernel form (attn_layer_i8.h, <= 128 tokens)
 // cannot hold on chip: up to 224 tokens (BASELINE configs[3]: T = 196).  Two kernels per layer:
 //
-//   qkv_i8q_kernel       Q/K/V projections (TM:71-73) on int8 slices, one 256-feature (= one head of Q, K or V) x 128-token
-//                        block per workgroup, results QUANTISED in the epilogue and written as the int8 operand images
+//   qkv_i8q_kernel       Q/K/V projections (TM:71-73) on int8 slices, one 256-feature (= one head of Q, K or V) x 64-token
+//                        block per workgroup, two workgroups per CU, results QUANTISED in the epilogue and written as the int8 operand images
 //                        of the core kernel: Q and K per row (query / key) with one scale each, V transposed with one
 //                        scale per key.  2 bytes per value go to memory instead of the 4 of the split-bf16 form — at
 //                        T = 196 the Q/K/V round trip (0.7 GB written, 1.2 GB read per layer at B = 256) is what bounds
@@ -44,30 +44,34 @@ EG_D void quant16v(const float v[16], const float inv[16], u32x4& s1, u32x4& s2)
     }
 }
 
-__global__ __launch_bounds__(256, 1) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o) {
+// 256 features (one head of Q, K or V) x 64 tokens per workgroup, four waves side by side along the features (64 each), 256
+// registers per wave: two workgroups share a CU, so one's prologue / epilogue meets the other's main loop.
+using Q8K = GemmCfg<2, 2, 4, 1, 1, 2, false, 2, 3>;
+using Q8V = GemmCfg<2, 2, 4, 1, 1, 2, true, 2, 3>;
+
+__global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int fblk, tblk;
     grouped_map(lid, (int)gridDim.x / a.ntb, a.ntb, fblk, tblk);
-    const int wave = wave_id_uniform();
+    const int wf = wave_id_uniform();  // feature quarter of the head
     const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
-    const int wf = wave & 1, wt = wave >> 1;
-    const int f0 = fblk * 256 + wf * 128, t0 = tblk * 128 + wt * 64;
+    const int f0 = fblk * 256 + wf * 64, t0 = tblk * 64;
     const int which = fblk * 256 / o.HD, h = (fblk * 256 % o.HD) >> 8;  // 0 = Q, 1 = K, 2 = V; head
     const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
-    float* red = (float*)smem;  // [2][128] cross-wave maxima; the main loop's ring is dead when it is used
-    I8Acc q[4][2];
-    f32x16 v[4][2];
+    float* red = (float*)smem;  // [4][64] cross-wave maxima; the main loop's ring is dead when it is used
+    I8Acc q[2][2];
+    f32x16 v[2][2];
     if (which < 2) {
         // ---- Q_h / K_h: lane owns a token; one scale per row; int8 image [token tile][d_k block]
-        GemmBody<AL8K, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        GemmBody<Q8K, NoEpi>::mainloop(g, fblk, tblk, smem, q);
         const float sc = which == 0 ? o.qscale : 1.0f;
-        float amax[2] = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float sa = a.h_scale[t0 + j * 32 + col];
+            float amax = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 i8_dequant(q[i][j], v[i][j], a.w_scale + f0 + i * 32 + 4 * hf, sa);
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
@@ -76,12 +80,12 @@ __global__ __launch_bounds__(256, 1) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         v[i][j][4 * gq + c] = (v[i][j][4 * gq + c] + bb[c]) * sc;
-                        amax[j] = fmaxf(amax[j], fabsf(v[i][j][4 * gq + c]));
+                        amax = fmaxf(amax, fabsf(v[i][j][4 * gq + c]));
                     }
                 }
             }
-            amax[j] = fmaxf(amax[j], __shfl_xor(amax[j], 32));
-            if (hf == 0) red[wf * 128 + wt * 64 + j * 32 + col] = amax[j];
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            if (hf == 0) red[wf * 64 + j * 32 + col] = amax;
         }
         __syncthreads();
         int8_t* dst8 = which == 0 ? o.q8 : o.k8;
@@ -91,34 +95,34 @@ __global__ __launch_bounds__(256, 1) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             const int m0 = t0 + j * 32;
             if (m0 >= o.Mvalid) continue;
             const int b = m0 / o.Lp, lt = (m0 % o.Lp) >> 5, bh = b * o.H + h;
-            const int tokb = wt * 64 + j * 32 + col;
-            const float rmax = fmaxf(red[tokb], red[128 + tokb]);
+            const int tokb = j * 32 + col;
+            const float rmax = fmaxf(fmaxf(red[tokb], red[64 + tokb]), fmaxf(red[128 + tokb], red[192 + tokb]));
             const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
             if (wf == 0 && hf == 0) dsts[(size_t)bh * o.Lp + lt * 32 + col] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 float t[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
                 u32x4 s1, s2;
                 quant16(t, inv, s1, s2);
-                int8_t* p = dst8 + ((((size_t)bh * o.KT + lt) * 8 + wf * 4 + i) << 10) + lane * 16;
+                int8_t* p = dst8 + ((((size_t)bh * o.KT + lt) * 8 + wf * 2 + i) << 10) + lane * 16;
                 *(u32x4*)p = s1;
                 *(u32x4*)(p + o.plane) = s2;
             }
         }
     } else {
         // ---- V_h: un-swapped accumulator (lane owns a feature, registers walk the tokens); one scale per KEY row
-        // (maximum over the head's 256 features: four tiles in-lane, 32 lanes by shuffles, two waves through LDS);
+        // (maximum over the head's 256 features: two tiles in-lane, 32 lanes by shuffles, four waves through LDS);
         // stored transposed [d_v tile][key block]
-        GemmBody<AL8V, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        GemmBody<Q8V, NoEpi>::mainloop(g, fblk, tblk, smem, q);
         float tmax[2][16];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax[j][r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const float sw = a.w_scale[f0 + i * 32 + col], bf = o.bias[f0 + i * 32 + col];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -137,9 +141,8 @@ __global__ __launch_bounds__(256, 1) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
                 float m = tmax[j][r];
 #pragma unroll
                 for (int s = 1; s < 32; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
-                tmax[j][r] = m;
                 // token of register r: 8 (r >> 2) + 4 hf + (r & 3) within tile j
-                if (col == 0) red[wf * 128 + wt * 64 + j * 32 + mfma32_row(r, hf)] = m;
+                if (col == 0) red[wf * 64 + j * 32 + mfma32_row(r, hf)] = m;
             }
         __syncthreads();
 #pragma unroll
@@ -150,19 +153,19 @@ __global__ __launch_bounds__(256, 1) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             float inv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int tokb = wt * 64 + j * 32 + mfma32_row(r, hf);
-                const float rmax = fmaxf(red[tokb], red[128 + tokb]);
+                const int tokb = j * 32 + mfma32_row(r, hf);
+                const float rmax = fmaxf(fmaxf(red[tokb], red[64 + tokb]), fmaxf(red[128 + tokb], red[192 + tokb]));
                 inv[r] = rmax > 0.f ? I8_QMAX / rmax : 0.f;
                 if (wf == 0 && col == 0) o.sv[(size_t)bh * o.Lp + lt * 32 + mfma32_row(r, hf)] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 float t[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
                 u32x4 s1, s2;
                 quant16v(t, inv, s1, s2);
-                int8_t* p = o.v8 + ((((size_t)bh * 8 + wf * 4 + i) * o.KT + lt) << 10) + lane * 16;
+                int8_t* p = o.v8 + ((((size_t)bh * 8 + wf * 2 + i) * o.KT + lt) << 10) + lane * 16;
                 *(u32x4*)p = s1;
                 *(u32x4*)(p + o.plane) = s2;
             }

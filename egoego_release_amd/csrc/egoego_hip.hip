@@ -450,15 +450,15 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 // outside the one-kernel form's range
                 {
                     ProfScope ps(c, EGOEGO_K_QKV, s);
-                    QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, tb_a, 2 * HD / BLK_A_F};
+                    QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, rows / 64, 2 * HD / BLK_A_F};
                     Qkv8Out qo{(int8_t*)w.Q, (int8_t*)w.K, (int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, L.b_qkv,
                                1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid};
                     static bool once = false;
                     if (!once) {
-                        HIP_TRY(allow_smem(qkv_i8q_kernel, AL8K::SMEM_BYTES));
+                        HIP_TRY(allow_smem(qkv_i8q_kernel, Q8K::SMEM_BYTES));
                         once = true;
                     }
-                    qkv_i8q_kernel<<<dim3((3 * HD / BLK_A_F) * tb_a), dim3(256), AL8K::SMEM_BYTES, s>>>(qa, qo);
+                    qkv_i8q_kernel<<<dim3((3 * HD / BLK_A_F) * (rows / 64)), dim3(256), Q8K::SMEM_BYTES, s>>>(qa, qo);
                     HIP_TRY(hipGetLastError());
                 }
                 {

@@ -170,9 +170,9 @@ struct TailChunk {
     }
 };
 
-// (Measured and NOT kept: the same kernel with 2 ring slots, 256 registers and two co-resident 64-token workgroups per CU for
-// B = 256 — 278 us per launch against the 225 us of layer_tail_kernel: with both the matrix pipe and the memory path
-// busy the chip clocks down to 1.45 GHz, and the LayerNorm epilogues of two lock-stepped workgroups collide.)
+// (Measured and NOT kept for B = 256: the same kernel with 2 ring slots, 256 registers and two co-resident 64-token workgroups per
+// CU — 278 us per launch against the 222 us of layer_tail_kernel, and no better with the second half of the grid started 20-80 us
+// late: a LayerNorm epilogue that takes 13 us alone takes 60 us next to a wave that saturates the matrix pipe of the same SIMD.)
 template <int TT>
 __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     constexpr int TOK = 32 * TT, FT = 4, NW = 2 * FT, RING = 4, PD = RING - 1;
