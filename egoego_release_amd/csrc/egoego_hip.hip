@@ -19,6 +19,10 @@
 #include "pointwise.h"
 #include "tail_fused.h"
 
+// hipcc drops the implicit instantiation of this kernel template when its only use sits in a nested branch of run_chunk_np
+// (the host object then references an undefined kernel handle): instantiate it explicitly.
+template __global__ void qkv_i8_kernel<EpiQK<2>, EpiV<2>>(QkvI8Args, EpiQK<2>, EpiV<2>);
+
 // ------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -342,6 +346,32 @@ static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
     return 0;
 }
 
+// Token-block size of the direct-operand embed / linear_out kernels (used while the 64-token grid fits the chip once).
+static int pick_tt(int rows) { return rows / 64 >= 256 ? 2 : 1; }
+
+template <int TT>
+static int launch_embed_tt(const EmbedArgs& ea, int rows, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        HIP_TRY(allow_smem(embed_kernel<TT>, TT * 32 * 1024));
+        once = true;
+    }
+    embed_kernel<TT><<<dim3(rows / (32 * TT)), dim3(256), TT * 32 * 1024, s>>>(ea);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <int TT>
+static int launch_out_tt(const OutArgs& oa, int rows, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        HIP_TRY(allow_smem(out_kernel<TT>, TT * 32 * 1024));
+        once = true;
+    }
+    out_kernel<TT><<<dim3(rows / (32 * TT)), dim3(256), TT * 32 * 1024, s>>>(oa);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int KT>
 static int launch_attn_core8_kt(const AttnCore8Args& a, int BH, hipStream_t s) {
     auto kern = attn_core_i8_kernel<KT>;
@@ -384,14 +414,21 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     if (w0 + nw >= g.B) rows = g.Mp - row0;  // the last chunk also carries the rows that pad Mp to the block size
     const int tb_a = rows / BLK_A_T, tb_b = rows / BLK_B_T, tb_c = rows / CfgC<NP>::BT;
     const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
-    const bool small_ln = tb_b < 200;  // below ~400 64-token blocks three separate kernels beat the fused tail (measured B = 32..192)
+    const bool small_ln = tb_b < 200;
+    const bool direct_io = rows / 64 < 256;  // embed / linear_out on the direct-operand kernels while the 64-token grid fits the chip once  // below ~400 64-token blocks three separate kernels beat the fused tail (measured B = 32..192)
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     // i8x3: windows of 97..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
     // layer reads the embed output as int8 rows
     const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;  // every layer input also as int8 rows
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
-        if (i8_path) {
+        if (NP == 2 && direct_io) {
+            // small grids: weights streamed into registers, activations by LDS-DMA chunks (tail_fused.h), same arithmetic
+            EmbedArgs ea{w.xall, w.xall_plane, c->KE / 16, c->w_embed, (size_t)N_MODEL * c->KE,
+                         EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, i8_path ? w.hA8 : nullptr,
+                                           w.h_plane, i8_path ? w.hA_scale : nullptr}};
+            if (int r = pick_tt(rows) == 2 ? launch_embed_tt<2>(ea, rows, s) : launch_embed_tt<1>(ea, rows, s)) return r;
+        } else if (i8_path) {
             // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
             EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
@@ -593,12 +630,17 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     }
     if (io.run_out) {
         ProfScope ps(c, EGOEGO_K_OUT, s);
-        GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c EG_DBG(, g_ablate, g_trace)};
-        EpiOut<NP> e{io.out};
-        if (tb_c <= SMALL_GRID) {
-            GemmOperands gs{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
-            if (int r = launch_gemm<CfgC2<NP>>(gs, e, s)) return r;
-        } else if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
+        if (NP == 2 && direct_io) {
+            OutArgs oa{w.hA, w.h_plane, c->w_out, (size_t)c->NOUT * N_MODEL, EpiOut<2>{io.out}};
+            if (int r = pick_tt(rows) == 2 ? launch_out_tt<2>(oa, rows, s) : launch_out_tt<1>(oa, rows, s)) return r;
+        } else {
+            GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c EG_DBG(, g_ablate, g_trace)};
+            EpiOut<NP> e{io.out};
+            if (tb_c <= SMALL_GRID) {
+                GemmOperands gs{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
+                if (int r = launch_gemm<CfgC2<NP>>(gs, e, s)) return r;
+            } else if (int r = launch_gemm<CfgC<NP>>(go, e, s)) return r;
+        }
     }
     return 0;
 }

@@ -46,12 +46,15 @@ struct TailArgs {
     EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][32] phase timestamps or nullptr
 };
 
-static constexpr int tail_smem_bytes(int TT) { return TT * 32 * 1024 + 3 * TT * 4 * 32 * TT * 4; }
+static constexpr int tail_smem_bytes(int TT) { return TT * 32 * 1024 + 3 * TT * 4 * 32 * TT * 4; }  // chunk double buffer + epilogue scratch
 
 // Weight / activation fragments are fetched through buffer resources: address = SGPR base + SGPR offset + one VGPR
 // (plain global loads make hipcc build a 64-bit VGPR address per fragment and k-step: hundreds of registers of them).
 using tail_rsrc = __amdgpu_buffer_rsrc_t;
-EG_D tail_rsrc tail_make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
+// `bytes`: extent of the tensor — loads past it return zeros (the weight prefetch of a short last chunk runs one k-block over)
+EG_D tail_rsrc tail_make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
+}
 EG_D i32x4 tail_load(tail_rsrc r, int voff, unsigned soff) {
     return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
@@ -65,11 +68,12 @@ EG_D i32x4 tail_load(tail_rsrc r, int voff, unsigned soff) {
 // k-step 0 through dma(piece) (loads return in order: issued first, they have the whole chunk to land).
 // Activation fragments: the hi plane is double-buffered (read a k-step ahead), the lo plane is re-read right after the
 // one MFMA group that uses it; each fragment is consumed >= FT*TT MFMAs after its read was issued.
-template <int FT, int TT, int RING, bool LAST, int DP>
+template <int FT, int TT, int RING, bool LAST, int DP, int NKS = 8>
 struct TailChunk {
-    static constexpr int PD = RING - 1, NW = FT * 2;
+    static constexpr int PD = RING - 1, NW = FT * 2;  // NKS < 8: the short last chunk of a contraction whose k-blocks are no multiple of 8
+    static_assert(NKS == 8 || (LAST && DP == 0), "only the last chunk may be short");
     static_assert(RING == 2 || RING == 4 || RING == 8, "ring slots must divide the 8 k-steps of a chunk");
-    static constexpr int n_ops(int s) { return ((s + PD < 8 || !LAST) ? NW : 0) + (s == 0 ? DP : 0); }
+    static constexpr int n_ops(int s) { return ((s + PD < NKS || !LAST) ? NW : 0) + (s == 0 ? DP : 0); }
     // vector-memory operations issued after the DMA pieces: what may stay in flight when the next chunk must have landed
     static constexpr int after_dma() {
         int n = 0;
@@ -101,7 +105,7 @@ struct TailChunk {
         asm volatile("" ::: "memory");
         wait_counts<allowed(KS), (KS == 0 ? 0 : TT)>();
         __builtin_amdgcn_sched_barrier(0);
-        if (KS + PD < 8 || !LAST) {
+        if (KS + PD < NKS || !LAST) {
             constexpr int kn = KS + PD;
 #pragma unroll
             for (int q = 0; q < NW; ++q)
@@ -112,7 +116,7 @@ struct TailChunk {
             for (int d = 0; d < DP; ++d)
                 if (!(TAIL_ABLATE & 4)) dma(d);
         }
-        if (KS < 7) {
+        if (KS < NKS - 1) {
 #pragma unroll
             for (int j = 0; j < TT; ++j)
                 if (!(TAIL_ABLATE & 2)) ah[cur ^ 1][j] = *(const i32x4*)(act + ((j * 8 + KS + 1) << 10) + lane * 16);
@@ -126,14 +130,14 @@ struct TailChunk {
 #pragma unroll
             for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i + 1], ah[cur][j], acc[i][j]);
         asm volatile("" ::: "memory");
-        wait_counts<63, (KS < 7 ? TT : 0)>();  // the lo-plane activations of this k-step
+        wait_counts<63, (KS < NKS - 1 ? TT : 0)>();  // the lo-plane activations of this k-step
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i], al[j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
-        if (KS < 7) {
+        if (KS < NKS - 1) {
 #pragma unroll
             for (int j = 0; j < TT; ++j)
                 if (!(TAIL_ABLATE & 2)) al[j] = *(const i32x4*)(act + act_plane + ((j * 8 + KS + 1) << 10) + lane * 16);
@@ -156,17 +160,80 @@ struct TailChunk {
             al[j] = *(const i32x4*)(act + act_plane + ((j * 8) << 10) + lane * 16);
         }
         step<0>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
-        step<1>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
-        step<2>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
-        step<3>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
-        step<4>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
-        step<5>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
-        step<6>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
-        step<7>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (NKS > 1) step<1>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (NKS > 2) step<2>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (NKS > 3) step<3>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (NKS > 4) step<4>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (NKS > 5) step<5>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (NKS > 6) step<6>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
+        if (NKS > 7) step<7>(acc, wq, ah, al, wr, wcur, wnext, act, act_plane, lane, dma);
         if (DP) {  // the next chunk has landed; the weight prefetches issued after its pieces stay in flight
             asm volatile("" ::: "memory");
             wait_counts<after_dma(), 15>();
         }
+    }
+};
+
+// ---- the GEMM: acc = in[32 TT tokens of this workgroup][K] x W[this wave's FT feature tiles][K]^T ------------------
+// in / w: split-bf16 fragment-tiled tensors with K16 = K / 16 k-blocks per row tile: a multiple of 8, or (REM2) a multiple of
+// 8 plus 2 — the embed operand's 26 k-blocks.  `act` is the
+// chunk double buffer in LDS (TT * 32 KiB).  Feature tile i of wave `wave` is tile wave * FT + i of W.
+template <int FT, int TT, int RING, bool REM2 = false>
+struct DirectGemm {
+    static constexpr int NW = 2 * FT, PD = RING - 1;
+    static constexpr int CH_PLANE = TT * 8 * 1024, CH_BYTES = 2 * CH_PLANE;  // chunk buffer: [plane][t-tile][8 k-blocks][1 KiB]
+    static constexpr int DMA_PIECES = 4 * TT;                                // 1-KiB pieces of a chunk per wave
+    static constexpr int SMEM_BYTES = 2 * CH_BYTES;
+
+    template <class Mark>
+    static EG_D void run(f32x16 (&acc)[FT][TT], const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, char* act,
+                         int tt0, int wave, int lane, Mark mark) {
+        i32x4 wq[RING][NW];
+        const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4), ir = tail_make_rsrc(in, in_plane * 4);
+        const unsigned wpb = (unsigned)(w_plane * 2), ipb = (unsigned)(in_plane * 2);
+        const int NQ = REM2 ? K16 / 8 + 1 : K16 / 8;  // chunks, the last one 2 k-steps long with REM2
+        auto w_offsets = [&](int kb, unsigned (&out)[NW]) {
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) out[2 * i + s] = s * wpb + (unsigned)(((wave * FT + i) * K16 + kb) << 10);
+        };
+        auto dma_piece = [&](int q, int piece) {
+            const int x = wave * DMA_PIECES + piece;  // flat index over [plane][t-tile][8 k-blocks]
+            const int s = x / (8 * TT), j = (x >> 3) % TT;
+            int kb = x & 7;
+            if (REM2 && q == NQ - 1) kb &= 1;  // the short chunk has 2 k-blocks: the other pieces re-load them (the counted waits assume a fixed piece count)
+            const unsigned src = s * ipb + (unsigned)(((tt0 + j) * K16 + 8 * q + kb) << 10);
+            char* dst = act + (q & 1) * CH_BYTES + s * CH_PLANE + ((j * 8 + kb) << 10);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ir, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, src, 0, 0);
+        };
+        unsigned wcur[NW], wnext[NW];
+#pragma unroll
+        for (int pc = 0; pc < DMA_PIECES; ++pc) dma_piece(0, pc);
+        w_offsets(0, wcur);
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+#pragma unroll
+            for (int q = 0; q < NW; ++q) wq[k][q] = tail_load(wr, lane * 16, wcur[q] + (k << 10));
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mark();
+        for (int q = 0; q + 1 < NQ; ++q) {
+            w_offsets(8 * q, wcur);
+            w_offsets(8 * q + 8, wnext);
+            TailChunk<FT, TT, RING, false, DMA_PIECES>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
+                                                             [&](int piece) { dma_piece(q + 1, piece); });
+            // the next chunk has landed (counted wait inside run) and everyone is done with this one
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        w_offsets(8 * (NQ - 1), wcur);
+        TailChunk<FT, TT, RING, true, 0, (REM2 ? 2 : 8)>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
+        __syncthreads();  // every wave is done with the chunk buffers before the next GEMM's first DMA
     }
 };
 
@@ -175,12 +242,11 @@ struct TailChunk {
 // late: a LayerNorm epilogue that takes 13 us alone takes 60 us next to a wave that saturates the matrix pipe of the same SIMD.)
 template <int TT>
 __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
-    constexpr int TOK = 32 * TT, FT = 4, NW = 2 * FT, RING = 4, PD = RING - 1;
-    constexpr int CH_PLANE = TT * 8 * 1024, CH_BYTES = 2 * CH_PLANE;  // chunk buffer: [plane][t-tile][8 k-blocks][1 KiB]
-    constexpr int DMA_PIECES = 4 * TT;                                // 1-KiB pieces of a chunk per wave
+    constexpr int TOK = 32 * TT, FT = 4;
+    using G = DirectGemm<FT, TT, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const act = smem;
-    char* const red = smem + 2 * CH_BYTES;  // the LayerNorm epilogues' cross-wave reduction scratch
+    char* const red = smem + G::SMEM_BYTES;  // the LayerNorm epilogues' cross-wave reduction scratch
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63;
     const int tok0 = (int)blockIdx.x * TOK;
@@ -194,63 +260,14 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
         (void)i;
     };
     mark(0);
-
     f32x16 acc[FT][TT];
-    i32x4 wq[RING][NW];
-
-    // ---------------------------------------------------------------- GEMM: acc = in[tokens][K] x W[512][K]^T
-    auto w_offsets = [&](unsigned wplane_bytes, int K16, int kb, unsigned (&out)[NW]) {
-#pragma unroll
-        for (int i = 0; i < FT; ++i)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) out[2 * i + s] = s * wplane_bytes + (unsigned)(((wave * FT + i) * K16 + kb) << 10);
-    };
-    auto dma_piece = [&](tail_rsrc ir, unsigned iplane_bytes, int K16, int q, int piece) {
-        const int x = wave * DMA_PIECES + piece;  // flat index over [plane][t-tile][8 k-blocks]
-        const int s = x / (8 * TT), j = (x >> 3) % TT, kb = x & 7;
-        const unsigned src = s * iplane_bytes + (unsigned)(((tt0 + j) * K16 + 8 * q + kb) << 10);
-        char* dst = act + (q & 1) * CH_BYTES + s * CH_PLANE + ((j * 8 + kb) << 10);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ir, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, src, 0, 0);
-    };
-    auto gemm = [&](const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, int mark_id) {
-        const tail_rsrc wr = tail_make_rsrc(w), ir = tail_make_rsrc(in);
-        const unsigned wpb = (unsigned)(w_plane * 2), ipb = (unsigned)(in_plane * 2);
-        const int NQ = K16 / 8;
-        unsigned wcur[NW], wnext[NW];
-#pragma unroll
-        for (int pc = 0; pc < DMA_PIECES; ++pc) dma_piece(ir, ipb, K16, 0, pc);
-        w_offsets(wpb, K16, 0, wcur);
-#pragma unroll
-        for (int k = 0; k < PD; ++k)
-#pragma unroll
-            for (int q = 0; q < NW; ++q) wq[k][q] = tail_load(wr, lane * 16, wcur[q] + (k << 10));
-#pragma unroll
-        for (int i = 0; i < FT; ++i)
-#pragma unroll
-            for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        mark(mark_id);
-        for (int q = 0; q + 1 < NQ; ++q) {
-            w_offsets(wpb, K16, 8 * q, wcur);
-            w_offsets(wpb, K16, 8 * q + 8, wnext);
-            TailChunk<FT, TT, RING, false, DMA_PIECES>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
-                                                             [&](int piece) { dma_piece(ir, ipb, K16, q + 1, piece); });
-            // the next chunk has landed (counted wait inside run) and everyone is done with this one
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        w_offsets(wpb, K16, 8 * (NQ - 1), wcur);
-        TailChunk<FT, TT, RING, true, 0>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
-        __syncthreads();  // every wave is done with the chunk buffers (the epilogue's scratch sits behind them, but the next GEMM's first DMA does not)
-    };
     // epilogue structs carry the large-batch kernels' code; only the tokens-per-block template argument differs
     auto as_ln = [&](const EpiResLN<2, 4, 0>& e) {
         return EpiResLN<2, 4, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale};
     };
 
     // =============================================================== 1. fc + residual + LayerNorm (TM:92-93, 135)
-    gemm(a.o, a.o_plane, a.HD16, a.wfc, a.wfc_plane, 7);
+    G::run(acc, a.o, a.o_plane, a.HD16, a.wfc, a.wfc_plane, act, tt0, wave, lane, [&] { mark(7); });
     mark(1);
     as_ln(a.ln1).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
     // this workgroup's LayerNorm-1 rows must have reached L2 before its LDS-DMAs of them
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     if (a.stop == 1) return;
 
     // =============================================================== 2. FFN w_1 + ReLU (TM:111)
-    gemm(a.ln1.out, a.ln1.out_plane, 32, a.w1, a.w1_plane, 8);
+    G::run(acc, a.ln1.out, a.ln1.out_plane, 32, a.w1, a.w1_plane, act, tt0, wave, lane, [&] { mark(8); });
     mark(3);
     a.relu.template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -269,9 +286,51 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     if (a.stop == 2) return;
 
     // =============================================================== 3. FFN w_2 + residual + LayerNorm (TM:111-114, 139)
-    gemm(a.relu.out, a.relu.out_plane, 32, a.w2, a.w2_plane, 9);
+    G::run(acc, a.relu.out, a.relu.out_plane, 32, a.w2, a.w2_plane, act, tt0, wave, lane, [&] { mark(9); });
     mark(5);
     as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
     EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
     mark(6);
+}
+
+// ---- embed and linear_out on the same operand path -----------------------------------------------------------------
+// One 4-wave workgroup per 32 TT tokens, one per CU.  embed (TM:199-216): 512 features, a wave owns 128 of them (FT = 4),
+// epilogue EpiEmbed (bias, position embedding, time token, optional int8 rows).  linear_out + DDPM posterior (M:139,
+// 235-256): 256 (= padded 198) features, a wave owns 64 (FT = 2), epilogue EpiOut.  Same MFMA order per output element
+// and same epilogue code as the LDS-ring kernels they replace: same bits.
+struct EmbedArgs {
+    const __bf16* x;   // embed operand [Mp][KE], split-bf16 fragment-tiled
+    size_t x_plane;
+    int K16;
+    const __bf16* w;   // [512][KE]
+    size_t w_plane;
+    EpiEmbed<2, 4, 0> epi;
+};
+template <int TT>
+__global__ __launch_bounds__(256, 1) void embed_kernel(EmbedArgs a) {
+    using G = DirectGemm<4, TT, 4, true>;  // the embed operand has 26 k-blocks (2 x 208 columns)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
+    f32x16 acc[4][TT];
+    G::run(acc, a.x, a.x_plane, a.K16, a.w, a.w_plane, smem, (int)blockIdx.x * TT, wave, lane, [] {});
+    const EpiEmbed<2, 4, 32 * TT> e{a.epi.bias, a.epi.pe, a.epi.tt_table, a.epi.t_idx, a.epi.out, a.epi.out_plane, a.epi.Lp, a.epi.T, a.epi.B,
+                                    a.epi.q8, a.epi.q8_plane, a.epi.q8_scale};
+    e.template run<4, TT>(acc, wave * 128, (int)blockIdx.x * 32 * TT, lane, wave, 0, smem);
+}
+
+struct OutArgs {
+    const __bf16* h;   // last layer's output [Mp][512]
+    size_t h_plane;
+    const __bf16* w;   // [256][512] (rows >= d_feats zero)
+    size_t w_plane;
+    EpiOut<2> epi;
+};
+template <int TT>
+__global__ __launch_bounds__(256, 1) void out_kernel(OutArgs a) {
+    using G = DirectGemm<2, TT, 4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
+    f32x16 acc[2][TT];
+    G::run(acc, a.h, a.h_plane, 32, a.w, a.w_plane, smem, (int)blockIdx.x * TT, wave, lane, [] {});
+    a.epi.template run<2, TT>(acc, wave * 64, (int)blockIdx.x * 32 * TT, lane, wave, 0, smem);
 }
