@@ -8,7 +8,7 @@
 //                        T = 196 the Q/K/V round trip (0.7 GB written, 1.2 GB read per layer at B = 256) is what bounds
 //                        the split-bf16 pair.
 //   attn_core_i8_kernel  one 4-wave workgroup per (window, head, block of 4 query tiles): the head's K image
-//                        (<= 112 KiB) comes into LDS by LDS-DMA, S^T = K Q^T on int8 MFMAs with the queries' Q
+//                        (<= 112 KiB) comes through LDS in two halves by LDS-DMA, S^T = K Q^T on int8 MFMAs with the queries' Q
 //                        fragments in registers, softmax in-lane (TM:76-82), P * (V's key scales) quantised per query
 //                        into registers, the V^T image over the K image, O^T = V^T P, 1/rowsum, split-bf16 store.
 //
@@ -182,12 +182,16 @@ struct AttnCore8Args {
     int HD16, H, L, Lp;
 };
 
+// The K image (d_k halves) and the V^T image (d_v halves) pass through two LDS buffers of KT * 8 KiB x 2 slices each, the next
+// half requested while the current one is multiplied: only the first K half is waited for with nothing to do.  S accumulates
+// over the two d_k halves in the same int32 accumulators (the row scales of K and Q cover the whole d_k).
 template <int KT>
 __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
-    constexpr int IMG = KT * 8 * 1024;  // bytes of one slice of the K (or V^T) image
+    constexpr int HALF = KT * 4 * 1024;  // bytes of one slice of half an image (4 of the 8 d blocks x KT tiles)
+    constexpr int BUF = 2 * HALF;        // one buffer: both slices of a half image
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kv = smem;                           // [slice][...]
-    float* sk = (float*)(smem + 2 * IMG);      // [KT*32] key scales of K
+    char* kv = smem;                           // [2 buffers][slice][half image]
+    float* sk = (float*)(smem + 2 * BUF);      // [KT*32] key scales of K
     float* sv = sk + KT * 32;                  // [KT*32] key scales of V
     const int bh = (int)blockIdx.y, qb = (int)blockIdx.x;
     const int b = bh / a.H, h = bh - b * a.H;
@@ -198,15 +202,30 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     const int qt = active ? qt_raw : KT - 1;
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)a.k8, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)a.v8, 0, 0x7fffffff, 0x00020000);
-    // ---- K image -> LDS (LDS-DMA, KT*16 pieces of 1 KiB over the four waves); Q fragments and scales -> registers
-    auto dma_image = [&](__amdgpu_buffer_rsrc_t r) {
-        for (int pc = wave; pc < KT * 16; pc += 4) {
-            const int s = pc / (KT * 8), blk = pc - s * KT * 8;
-            const unsigned src = (unsigned)(s * a.plane) + (unsigned)(((size_t)bh * KT * 8 + blk) << 10);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(kv + s * IMG + (blk << 10)), 16, lane * 16, src, 0, 0);
+    constexpr int NPIECE = KT * 8 / 4;  // 1-KiB pieces of a half image (both slices) per wave: KT*4 blocks x 2 slices / 4 waves
+    // K image [kt][8 d blocks]: half `hh` = d blocks 4hh .. 4hh+3 of every key tile -> buffer layout [kt][4]
+    auto dma_k_half = [&](int hh, int buf) {
+#pragma unroll
+        for (int n = 0; n < NPIECE; ++n) {
+            const int pc = n * 4 + wave;
+            const int s = pc / (KT * 4), blk = pc - s * KT * 4, kt = blk >> 2, i = blk & 3;
+            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((((size_t)bh * KT + kt) * 8 + 4 * hh + i) << 10);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + s * HALF + (blk << 10)), 16,
+                                                     lane * 16, src, 0, 0);
         }
     };
-    dma_image(kr);
+    // V^T image [8 d_v tiles][kt]: half `hh` = d_v tiles 4hh .. 4hh+3 -> contiguous
+    auto dma_v_half = [&](int hh, int buf) {
+#pragma unroll
+        for (int n = 0; n < NPIECE; ++n) {
+            const int pc = n * 4 + wave;
+            const int s = pc / (KT * 4), blk = pc - s * KT * 4;
+            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((((size_t)bh * 8 + 4 * hh) * KT + blk) << 10);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + s * HALF + (blk << 10)), 16,
+                                                     lane * 16, src, 0, 0);
+        }
+    };
+    dma_k_half(0, 0);
     for (int i = threadIdx.x; i < KT * 32; i += 256) {
         sk[i] = a.sk[(size_t)bh * a.Lp + i];
         sv[i] = a.sv[(size_t)bh * a.Lp + i];
@@ -221,8 +240,9 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     const float sq = a.sq[(size_t)bh * a.Lp + qt * 32 + col];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    dma_k_half(1, 1);
 
-    // ---- S^T = K Q^T, softmax over keys (TM:76-82), P * s_v quantised per query
+    // ---- S^T = K Q^T over the two d_k halves, softmax over keys (TM:76-82), P * s_v quantised per query
     i32x4 ps1[KT], ps2[KT];
     float oscale;
     {
@@ -230,20 +250,28 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc_zero(s[kt]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            i32x4 k1[KT], k2[KT];
+        for (int hh = 0; hh < 2; ++hh) {
+            const char* img = kv + hh * BUF;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const char* src = kv + ((kt * 8 + i) << 10) + lane * 16;
-                k1[kt] = lds_frag(src);
-                k2[kt] = lds_frag(src + IMG);
+            for (int i = 0; i < 4; ++i) {
+                i32x4 k1[KT], k2[KT];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const char* src = img + ((kt * 4 + i) << 10) + lane * 16;
+                    k1[kt] = lds_frag(src);
+                    k2[kt] = lds_frag(src + HALF);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k2[kt], qs1[4 * hh + i], s[kt].m, 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs2[4 * hh + i], s[kt].m, 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs1[4 * hh + i], s[kt].h, 0, 0, 0);
             }
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k2[kt], qs1[i], s[kt].m, 0, 0, 0);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs2[i], s[kt].m, 0, 0, 0);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) s[kt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs1[i], s[kt].h, 0, 0, 0);
+            // the buffer every wave has finished with takes the next V half; the second K half must have landed
+            if (hh == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            dma_v_half(hh, hh);
         }
         float p[KT][16];
         float mx = -INFINITY;
@@ -292,16 +320,15 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
             ps2[kt] = __builtin_bit_cast(i32x4, s2);
         }
     }
-    // ---- V^T image over the K image (every wave is done with K)
-    __syncthreads();
-    dma_image(vr);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
-    // ---- O^T = V^T P (TM:83-88), heads merged on store
+    // ---- O^T = V^T P (TM:83-88) per d_v half, heads merged on store
     const int m = b * a.Lp + qt * 32 + col;
 #pragma unroll 1
     for (int dvh = 0; dvh < 2; ++dvh) {
+        // this half has landed: all pieces of half 0 were issued before those of half 1 (loads return in order)
+        if (dvh == 0) wait_counts<NPIECE, 15>(); else wait_counts<0, 15>();
+        __syncthreads();
+        const char* img = kv + dvh * BUF;
         I8Acc o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) acc_zero(o[dt]);
@@ -310,9 +337,9 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
             i32x4 v1[4], v2[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char* src = kv + (((dvh * 4 + dt) * KT + kb) << 10) + lane * 16;
+                const char* src = img + ((dt * KT + kb) << 10) + lane * 16;
                 v1[dt] = lds_frag(src);
-                v2[dt] = lds_frag(src + IMG);
+                v2[dt] = lds_frag(src + HALF);
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], ps1[kb], o[dt].m, 0, 0, 0);

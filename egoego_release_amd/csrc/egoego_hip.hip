@@ -375,7 +375,7 @@ static int launch_out_tt(const OutArgs& oa, int rows, hipStream_t s) {
 template <int KT>
 static int launch_attn_core8_kt(const AttnCore8Args& a, int BH, hipStream_t s) {
     auto kern = attn_core_i8_kernel<KT>;
-    constexpr int smem = 2 * KT * 8 * 1024 + 2 * KT * 32 * 4;
+    constexpr int smem = 2 * (2 * KT * 4 * 1024) + 2 * KT * 32 * 4;  // two buffers of half an image (both slices) + key scales
     static bool once = false;
     if (!once) {
         HIP_TRY(allow_smem(kern, smem));
