@@ -114,6 +114,9 @@ static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g) {
     else if (g.L <= 224) g.KT = 7;
     else return fail(EGOEGO_E_INVALID, "window length T=%d not supported (T+1 must be <= 224)", T);
     g.Lp = 32 * g.KT;
+    // 32-bit byte offsets into one operand plane (buffer-resource addressing, rows x 2 KiB at most): 2^20 padded rows per call
+    if ((size_t)B * g.Lp > (size_t)1 << 20)
+        return fail(EGOEGO_E_INVALID, "B=%d windows of %d padded rows exceed 1048576 rows per call: split the batch", B, g.Lp);
     g.Mvalid = B * g.Lp;
     g.Mp = (int)align_up((size_t)g.Mvalid, 256);
     return 0;

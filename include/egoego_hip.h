@@ -112,7 +112,10 @@ void egoego_ctx_destroy(egoego_ctx* ctx);
 int egoego_load_weights(egoego_ctx* ctx, const egoego_weights* w, void* stream);
 int egoego_load_schedule(egoego_ctx* ctx, const egoego_schedule* s, void* stream);
 
-/* Bytes of scratch a call with batch B and window length T needs (256-byte aligned base). */
+/* Bytes of scratch a call with batch B and window length T needs (256-byte aligned base).
+ * Returns 0 (egoego_last_error() says why) for shapes no call accepts: T + 1 > 224 or > max_timesteps, or more than
+ * 2^20 padded rows per call (B * 32 * ceil((T + 1) / 32); T + 1 in 129..224 pads to 224): B <= 8192 at T = 120,
+ * B <= 4681 at T = 196 — split larger batches, windows are independent. */
 size_t egoego_workspace_bytes(const egoego_ctx* ctx, int B, int T);
 
 /* Replaces TransformerDiffusionModel.forward on cat(x, x_cond) (M:118-141, 232-233):

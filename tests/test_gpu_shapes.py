@@ -190,3 +190,35 @@ def test_pred_noise_objective_all_timesteps(prec):
         err = (got - want).abs().max().item()
         bound = POSE_TOL if tval <= 980 else 2 * sched["posterior_mean_coef1"][tval].item() + 1e-4
         assert err < bound, (tval, err)
+
+
+@pytest.mark.parametrize("B,T", [(2048, 120), (1024, 196), (8192, 120), (4680, 196)])
+def test_large_batches_match_the_same_windows_in_small_runs(B, T):
+    """Beyond BASELINE's sizes (288 GB of HBM take thousands of windows per call): windows at both ends and across the middle
+    of a 2048-window (T=120) / 1024-window (T=196) batch equal, bit for bit, the same windows run four at a time at their
+    global offset — index arithmetic of every kernel at 262144 / 229376 padded rows and at the largest accepted calls
+    (8192 windows at T=120 = 2^20 rows, ≈27 GB of workspace; 4680 at T=196) — and one of them is checked against the oracle.  Row counts above 2^20 per call are refused."""
+    cfg, sd, m = _model(T=T, precision=_lib.PREC_I8X3)
+    eng = m.hip_engine()
+    xs, cm = make_head_windows(8, T, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x0 = torch.randn((B, T, 198), generator=g, device="cuda")
+    xc = (xs * (1 - cm)).cuda().repeat(B // 8, 1, 1) + torch.randn((B, T, 198), generator=g, device="cuda") * cm.cuda().repeat(B // 8, 1, 1)
+    a = x0.clone()
+    eng.sample_loop_(a, xc, 999, 3, noise_mode=_lib.NOISE_PHILOX, seed=3)
+    assert torch.isfinite(a).all()
+    for off in (0, B // 2 - 2, B - 4):
+        sh = x0[off:off + 4].clone()
+        eng.sample_loop_(sh, xc[off:off + 4].contiguous(), 999, 3, noise_mode=_lib.NOISE_PHILOX, seed=3, window_offset=off)
+        assert torch.equal(sh, a[off:off + 4]), off
+    # one denoiser pass of the last window against the oracle
+    t = torch.full((B,), 500, device="cuda", dtype=torch.long)
+    y = eng.denoise(x0, xc, t)
+    with torch.no_grad():
+        ref = O.denoise(sd, torch.cat((x0[-1:].cpu(), xc[-1:].cpu()), -1), torch.tensor([500]))
+    assert (y[-1:].cpu() - ref).abs().max().item() < POSE_TOL
+    del a, y
+    Lp = 128 if T == 120 else 224
+    nb = (1 << 20) // Lp + 1
+    with pytest.raises(_lib.EgoEgoHipError, match="split the batch"):
+        eng.workspace(nb, T)
