@@ -37,7 +37,15 @@ class Shim:
         return getattr(TF, n)
 
     def _r(self, x, w):
-        return x.to(self.act_dtype).float() if (self.act_dtype is not None and id(w) in self.marked) else x
+        if self.act_dtype is None or id(w) not in self.marked:
+            return x
+        if self.act_dtype == "i8x2":  # two int8 slices: 15-bit integers, one scale per row (per row AND head for the fc input)
+            rows = x if x.shape[-1] in (512, 1024, 396) else x.transpose(1, 2)  # conv1d takes [B, C, L]
+            shp = rows.shape
+            grp = rows.reshape(shp[:-1] + (-1, 256)) if shp[-1] == 1024 else rows.reshape(shp[:-1] + (1, shp[-1]))
+            q = quant15(grp, -1).reshape(shp)
+            return q if rows is x else q.transpose(1, 2)
+        return x.to(self.act_dtype).float()
 
     def linear(self, x, w, b=None):
         return TF.linear(self._r(x, w), w, b)
@@ -46,12 +54,24 @@ class Shim:
         return TF.conv1d(self._r(x, w), w, b)
 
 
+QMAX = 32639.0  # 127 * 256 + 127
+
+
+def quant15(x, dim):
+    amax = x.abs().amax(dim=dim, keepdim=True)
+    sc = torch.where(amax > 0, amax / QMAX, torch.ones_like(amax))
+    return torch.round(x / sc) * sc
+
+
 def run(names, w_dtype, act_dtype):
     sd2 = dict(sd)
     marked = set()
     for k in sd:
         if any(k.endswith(n) for n in names):
-            sd2[k] = sd[k].to(w_dtype).float() if w_dtype is not None else sd[k].clone()
+            if w_dtype == "i8x2":  # one scale per output feature (row of W)
+                sd2[k] = quant15(sd[k].reshape(sd[k].shape[0], -1), 1).reshape(sd[k].shape)
+            else:
+                sd2[k] = sd[k].to(w_dtype).float() if w_dtype is not None else sd[k].clone()
             marked.add(id(sd2[k]))
     O.F = Shim(marked, act_dtype)
     g = torch.Generator().manual_seed(123)
@@ -62,7 +82,12 @@ def run(names, w_dtype, act_dtype):
 
 torch.set_num_threads(8)
 ref = run((), None, None)
-for label, names, wd, ad in (("tail weights fp16, activations exact (f16x2)", TAIL, torch.float16, None),
+QKV = ("w_q.weight", "w_k.weight", "w_v.weight")
+for label, names, wd, ad in (("Q/K/V projections on two int8 slices (as shipped, projections only)", QKV, "i8x2", "i8x2"),
+                             ("tail GEMMs on two int8 slices", TAIL, "i8x2", "i8x2"),
+                             ("FFN GEMMs only on two int8 slices", TAIL[1:], "i8x2", "i8x2"),
+                             ("Q/K/V + tail GEMMs on two int8 slices", QKV + TAIL, "i8x2", "i8x2"),
+                             ("tail weights fp16, activations exact (f16x2)", TAIL, torch.float16, None),
                              ("tail weights and activations fp16 (f16x1)", TAIL, torch.float16, torch.float16),
                              ("tail weights bf16, activations exact", TAIL, torch.bfloat16, None),
                              ("all GEMM weights fp16, activations exact", ALL, torch.float16, None),
