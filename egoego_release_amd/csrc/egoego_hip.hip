@@ -349,8 +349,8 @@ static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
     return 0;
 }
 
-// Token-block size of the direct-operand embed / linear_out kernels (used while the 64-token grid fits the chip once).
-static int pick_tt(int rows) { return rows / 64 >= 256 ? 2 : 1; }
+// The direct-operand embed / linear_out kernels run 32-token workgroups (TT = 1) at every size they are used for
+// (64-token ones measured slower at B=128: 46 / 49 us against 40 / 38).
 
 template <int TT>
 static int launch_embed_tt(const EmbedArgs& ea, int rows, hipStream_t s) {
@@ -417,8 +417,8 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     if (w0 + nw >= g.B) rows = g.Mp - row0;  // the last chunk also carries the rows that pad Mp to the block size
     const int tb_a = rows / BLK_A_T, tb_b = rows / BLK_B_T, tb_c = rows / CfgC<NP>::BT;
     const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
-    const bool small_ln = tb_b < 200;
-    const bool direct_io = rows / 64 < 256;  // embed / linear_out on the direct-operand kernels while the 64-token grid fits the chip once  // below ~400 64-token blocks three separate kernels beat the fused tail (measured B = 32..192)
+    const bool small_ln = tb_b < 200;  // below ~400 64-token blocks three separate kernels beat the fused tail (split-bf16 precision; measured B = 32..192)
+    const bool direct_io = rows / 64 <= 256;  // embed / linear_out on the direct-operand kernels up to 128 windows of 128 rows (measured: B=128 40 / 38 us against 50 / 55 on the ring kernels, B=256 80 / 72 against 67 / 69)
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     // i8x3: windows of 97..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
     // layer reads the embed output as int8 rows
@@ -430,7 +430,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             EmbedArgs ea{w.xall, w.xall_plane, c->KE / 16, c->w_embed, (size_t)N_MODEL * c->KE,
                          EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, i8_path ? w.hA8 : nullptr,
                                            w.h_plane, i8_path ? w.hA_scale : nullptr}};
-            if (int r = pick_tt(rows) == 2 ? launch_embed_tt<2>(ea, rows, s) : launch_embed_tt<1>(ea, rows, s)) return r;
+            if (int r = launch_embed_tt<1>(ea, rows, s)) return r;
         } else if (i8_path) {
             // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
@@ -635,7 +635,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         ProfScope ps(c, EGOEGO_K_OUT, s);
         if (NP == 2 && direct_io) {
             OutArgs oa{w.hA, w.h_plane, c->w_out, (size_t)c->NOUT * N_MODEL, EpiOut<2>{io.out}};
-            if (int r = pick_tt(rows) == 2 ? launch_out_tt<2>(oa, rows, s) : launch_out_tt<1>(oa, rows, s)) return r;
+            if (int r = launch_out_tt<1>(oa, rows, s)) return r;
         } else {
             GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c EG_DBG(, g_ablate, g_trace)};
             EpiOut<NP> e{io.out};
