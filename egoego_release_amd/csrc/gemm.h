@@ -202,7 +202,7 @@ struct GemmBody {
         };
         // MFMAs of one half (FH x TT accumulator triples, part-major).  DMA instruction q of (stage, slot) is issued
         // after MFMA q - q0, so the DMA issue cost is paid in the shadow of the matrix pipe.
-        auto mfmas = [&](const ActFr& a, const WFr& w, int half, bool dma, int stage, int slot, int q0, auto&& after_first) {
+        auto mfmas = [&](const ActFr& a, const WFr& w, int half, bool dma, int stage, int slot, int q0, auto&& after_first, auto&& reads) {
             constexpr int NPART = NP == 2 ? 3 : 1;
             constexpr int NMMA = NPART * FH * TT;
             constexpr int PER = (NCH + 2 * NMMA - 1) / (2 * NMMA);
@@ -215,6 +215,7 @@ struct GemmBody {
                         mma_part<NP, C::ACT_ROWS>(part, acc[half * FH + i][j], w.h[i], w.l[i], a.h[j], a.l[j]);
                         const int n = (part * FH + i) * TT + j;
                         if (n == 0) after_first();
+                        reads(n);
 #pragma unroll
                         for (int q = 0; q < PER; ++q)
                             if (q0 + n * PER + q < NCH && dma) {
@@ -261,11 +262,12 @@ struct GemmBody {
             for (int j = 0; j < NCH; ++j) issue_one(D, D, j);
         }
         auto nothing = [] {};
+        auto noreads = [](int) {};
         read_act(0, 0, a0);
         read_w(0, 0, 0, w0);
         read_w(0, 0, 1, w1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(a0, w0, 0, false, 0, 0, 0, nothing);
+        mfmas(a0, w0, 0, false, 0, 0, 0, nothing, noreads);
         // LDS reads are only ever waited for with NOTHING younger in flight: a batch is issued, a full batch of
         // MFMAs on operands already in registers runs, and the wait (hipcc puts an lgkmcnt(0) before the first
         // use, or the explicit one below) then finds the data there.  W-half1 is therefore read right AFTER the
@@ -282,16 +284,41 @@ struct GemmBody {
                 wait_lds();  // W-half1 of the previous k-step (issued 11 MFMAs ago): tell hipcc it has landed
             }
             __builtin_amdgcn_sched_barrier(0);
-            read_act(slot, ks, acur);
-            read_w(slot, ks, 0, w0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(aprev, w1, 1, dma, st - 1 + NS, pslot, 0, nothing);
+            {
+                // The k-step's first fragments (activations + first half of the weight tiles) go out two at a time behind the first
+                // MFMAs of the previous half instead of as one burst in front of them: a lone wave per SIMD issues nothing else
+                // while a burst of ds_reads goes out (measured at B=256: attention layer -2.6 %, tail -0.7 %; one or three per
+                // MFMA, or spreading the second half's reads as well, measured no better).
+                constexpr int NRD = NP * (TT + FH), PER = 2;
+                const char* sb = smem + (size_t)slot * C::STAGE_BYTES + lane * 16;
+                auto one_read = [&](int r) {
+                    if (!reads_on) return;
+                    if (r < NP * TT) {
+                        const int p = r / TT, j = r - p * TT;
+                        const bf16x8 v = *(const bf16x8*)(sb + ((WT * NP + p * AT + wt * TT + j) * KS + ks) * 1024);
+                        if (p == 0) acur.h[j] = v; else acur.l[j] = v;
+                    } else {
+                        const int q = r - NP * TT, p = q / FH, i = q - p * FH;
+                        const bf16x8 v = *(const bf16x8*)(sb + ((p * WT + wf * FT + i) * KS + ks) * 1024);
+                        if (p == 0) w0.h[i] = v; else w0.l[i] = v;
+                    }
+                };
+                mfmas(aprev, w1, 1, dma, st - 1 + NS, pslot, 0, nothing, [&](int n) {
+                    if (PER * n < NRD) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < PER; ++e)
+                            if (PER * n + e < NRD) one_read(PER * n + e);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            }
             __builtin_amdgcn_sched_barrier(0);
             mfmas(acur, w0, 0, dma, st - 1 + NS, pslot, DMA_PER_HALF, [&] {
                 __builtin_amdgcn_sched_barrier(0);
                 read_w(slot, ks, 1, w1);
                 __builtin_amdgcn_sched_barrier(0);
-            });
+            }, noreads);
             __builtin_amdgcn_sched_barrier(0);
         };
         int kk = 1;
@@ -301,9 +328,9 @@ struct GemmBody {
         }
         if (kk < nu) {
             unit(kk, a1, a0);
-            mfmas(a1, w1, 1, false, 0, 0, 0, nothing);
+            mfmas(a1, w1, 1, false, 0, 0, 0, nothing, noreads);
         } else {
-            mfmas(a0, w1, 1, false, 0, 0, 0, nothing);
+            mfmas(a0, w1, 1, false, 0, 0, 0, nothing, noreads);
         }
         __syncthreads();
         EG_DBG(if (g.trace && threadIdx.x == 0) {
