@@ -2,6 +2,7 @@
 """Headline benchmark: stage-2 diffusion sampling steps/sec on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py --gpus N ...            (starts its own ranks: a child `python -m torch.distributed.run`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,14 +11,18 @@ the GLOBAL batch of B=256 windows of T=120 frames x 198 features with inputs res
 the batch is split (egoego_release_amd.dist: contiguous window shards, no data-path collective; STRONG
 scaling) and one RCCL all_gather of the poses to every rank closes the timed region.
 Rank 0 prints ONE JSON line.
+
+Environment: EGOEGO_DIST_BACKEND=gloo lets several ranks share one GPU (tests on a 1-GPU box; default "nccl" = RCCL);
+EGOEGO_FORCE_COLLECTIVE=1 initialises the process group and runs the all_gather even with ONE rank, so that RCCL
+init + the collective execute on a 1-GPU box.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -46,6 +51,7 @@ def tail_flops_per_launch(B, T, d_model=512, n_head=4, d_k=256):
 
 
 def cpu_baseline(cfg, sd, B, T, budget_s=25.0):
+    import torch
     """Time the CPU oracle (fp32 PyTorch restatement of the reference, bit-identical to it) on the
     host cores: whole-batch p_sample steps until ~budget_s of work."""
     from oracle import egoego_oracle as O
@@ -85,6 +91,27 @@ def cpu_baseline(cfg, sd, B, T, budget_s=25.0):
             "ms_per_step": 1e3 * el / n}
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """Run this very command under torch.distributed.run with n ranks in a child process and relay its output."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL / cross-process tensors)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,24 +127,34 @@ def main():
     ap.add_argument("--dump", default=None, help="rank 0 saves the gathered poses of the timed call here (tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (this parent never touches the
+        # GPU and never execs), relay what they print and exit with the launcher's code
+        return self_launch(args.gpus)
+    import torch
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     backend = os.environ.get("EGOEGO_DIST_BACKEND", "nccl")  # "gloo" lets two ranks share one GPU (1-GPU test of this path)
-    if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
+    force_coll = os.environ.get("EGOEGO_FORCE_COLLECTIVE", "0") == "1"
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, {ndev} visible (EGOEGO_DIST_BACKEND=gloo shares GPUs between ranks)")
+    local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or force_coll:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -136,7 +173,7 @@ def main():
     model.hip_precision = args.precision
     model.hip_graph = not args.no_graph
     model = model.to(dev)
-    eng = model.hip_engine()
+    eng = model.hip_engine(verify=True)
 
     # the GLOBAL batch (every rank holds it: 24 MB per tensor at B=256); rank r samples the contiguous slice
     # dist.shard_bounds gives it (strong scaling: BASELINE configs[2] is B=256 split over the GPUs of the node)
@@ -150,25 +187,32 @@ def main():
     if K + W > S:
         raise SystemExit(f"steps + warmup must not exceed the {S}-step chain")
 
-    # warm-up: W untimed steps through the very path that is timed (packs the workspace, captures the step graph)
+    # warm-up: W untimed steps through the very path that is timed (packs the workspace, captures the step graph,
+    # and runs the collective once so that RCCL's lazy communicator set-up is not in the timed region)
     if W:
-        D.sample_sharded(D.hip_steps_fn(model, S - 1, W, seed=7), xs, cm, noise)
+        D.sample_sharded(D.hip_steps_fn(model, S - 1, W, seed=7), xs, cm, noise, force_collective=force_coll)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # K steps of this rank's shard (no collective in the loop), then the ONE all_gather of the path
-    out = D.sample_sharded(D.hip_steps_fn(model, S - 1 - W, K, seed=7), xs, cm, noise)
+    # K steps of this rank's shard (no collective in the loop) ...
+    shard = D.sample_local(D.hip_steps_fn(model, S - 1 - W, K, seed=7), xs, cm, noise)
     torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    # ... then the ONE all_gather of the path (timed separately as well)
+    out = D.gather_windows(shard, B, force=force_coll) if dist else shard
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    gather_ms, sample_ms = 1e3 * (t2 - t1), 1e3 * (t1 - t0)
     if dist:
-        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([el, gather_ms, sample_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = tmax.item()
+        el, gather_ms, sample_ms = tmax.tolist()
     finite = bool(torch.isfinite(out).all().item()) and tuple(out.shape) == (B, T, cfg.d_feats)
     if args.dump and rank == 0:
         torch.save(out.cpu(), args.dump)
@@ -178,8 +222,8 @@ def main():
     Bl = hi - lo
     x_l = noise["x_T"][lo:hi].contiguous().clone()
     xc_l = (xs[lo:hi] * (1 - cm[lo:hi]) + cm[lo:hi] * noise["cond"][lo:hi]).contiguous()
-    kern = {}
-    for name in ("qkv", "fc_ln"):
+    kern = {"qkv": (0.0, 0), "fc_ln": (0.0, 0)}
+    for name in (("qkv", "fc_ln") if Bl else ()):  # (a rank can be empty when there are fewer windows than ranks)
         eng.profile_begin(name)
         eng.sample_loop_(x_l, xc_l, S - 1 - W, min(K, 20), noise_mode=_lib.NOISE_PHILOX, seed=7, window_offset=lo)
         torch.cuda.synchronize()
@@ -188,12 +232,16 @@ def main():
 
     traffic, traffic_src = {}, None
     try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command, summarised under profiles/
-        tp = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        with open(tp) as f:
-            tj = json.load(f)
-        if (Bl, T, args.precision) == (tj.get("batch"), tj.get("window"), tj.get("precision")):
-            traffic = tj["kernels"]
-            traffic_src = "profiles/r02_traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)"
+        for name in ("r03_traffic.json", "r02_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(tp):
+                continue
+            with open(tp) as f:
+                tj = json.load(f)
+            if (Bl, T, args.precision) == (tj.get("batch"), tj.get("window"), tj.get("precision")):
+                traffic = tj["kernels"]
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc passes of this command; not measured in this run)"
+                break
     except Exception:
         traffic = {}
 
@@ -222,7 +270,9 @@ def main():
             "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time, measured on rank 0's shard right after "
                     "the timed region; three MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe "
                     "utilisation is 3x this fraction"}
-        tail_name = "layer_tail_kernel" if Bl * (T + 1 + 31) // 32 * 32 // 128 > 128 and Bl >= 200 else "tail_kernel"
+        Lp = 32 if L <= 32 else 64 if L <= 64 else 128 if L <= 128 else 224       # padded rows per window (make_geometry)
+        rows_p = (Bl * Lp + 255) // 256 * 256                                     # padded token rows of this rank's shard
+        tail_name = "layer_tail_kernel" if rows_p // 128 > 128 else "tail_kernel"  # the library's dispatch (run_chunk_np: tb_b <= 128 -> tail_kernel)
         tail_roof = {
             "bound": "mfma", "kernel": tail_name + (" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, two workgroups per CU, "
                                                     "LDS-ring operands, split-bf16)" if tail_name == "layer_tail_kernel" else
@@ -258,6 +308,10 @@ def main():
             "step_tflops_algorithmic": fl_step * steps_per_s / 1e12,
             "step_frac_of_bf16_peak": fl_step * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS,
             "output_finite": finite,
+            "rccl_ranks": (dist.get_world_size() if dist and backend == "nccl" else 0),
+            "collective_backend": (backend if dist else None),
+            "gather_ms": gather_ms if dist else None,
+            "sample_ms": sample_ms,
             "roofline": dominant,
             "roofline_second_kernel": other,
         }
@@ -273,4 +327,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

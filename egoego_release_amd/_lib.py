@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegoego_hip.so")
 PERFDEBUG_LIB_PATH = os.path.join(_PKG, "libegoego_hip_perfdebug.so")  # tools/ only: `build --perfdebug`
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_NO_GRAPH = 1
 PRED_NOISE, PRED_X0 = 0, 1
 NOISE_INJECTED, NOISE_PHILOX, NOISE_NONE = 0, 1, 2
@@ -88,8 +88,8 @@ def load():
     lib.egoego_workspace_bytes.restype = sz
     lib.egoego_denoise.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]
     lib.egoego_p_sample.argtypes = [vp, vp, vp, vp, vp, vp, i32, u64, i64, i32, i32, i32, vp, sz, vp]
-    lib.egoego_sample_loop.argtypes = [vp, vp, vp, i32, i32, vp, i32, u64, i64, vp, i32, i32, i32, vp, sz, vp]
-    lib.egoego_ddim_loop.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, sz, vp]
+    lib.egoego_sample_loop.argtypes = [vp, vp, vp, i32, i32, vp, i32, u64, i64, vp, i32, vp, i32, i32, vp, sz, vp]
+    lib.egoego_ddim_loop.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), i32, C.c_float, vp, i32, u64, i64, i32, i32, vp, sz, vp]
     lib.egoego_rot6d_to_matrix.argtypes = [vp, vp, i64, vp]
     lib.egoego_convert_model_res.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int32), i32, i32, i32, vp, vp, vp, vp]
     lib.egoego_window_condition.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]

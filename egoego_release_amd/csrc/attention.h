@@ -1,5 +1,5 @@
 // attention.h — full (unmasked) multi-head self-attention over one window, split-bf16 MFMA.
-// (The i8x3 precision replaces this and the QKV projection by attn_layer_i8.h for windows of 97..128 tokens;
+// (The i8x3 precision replaces this and the QKV projection by attn_layer_i8.h for windows of 65..128 tokens;
 // this kernel serves the split-bf16 precision and every other window length.)
 //
 // Replaces TM:75-88 (bmm, /temperature, softmax, bmm, head merge) for use_full_attention=True.

@@ -189,6 +189,23 @@ EG_D int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadI
 // row = (r & 3) + 8 * (r >> 2) + 4 * hf; the column is lane & 31.
 EG_D int mfma32_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
+// Step state of a multi-step loop, kept in device memory so that ONE captured step (hipGraph) replays for every
+// timestep of every chain on every caller buffer.  The step's first kernel (embed) reads embed_step and publishes
+// out_step = embed_step + 1; its last kernel (linear_out + posterior) reads out_step - 1 and publishes
+// embed_step = out_step for the next step: each counter is written by a launch whose blocks do not read it, so
+// there is no intra-launch race, and the stream orders the launches.
+struct StepState {
+    int embed_step;  // index of the step the next embed launch runs
+    int t_start;     // timestep of step 0 (ancestral chains: t = t_start - step)
+    int out_step;    // 1 + index of the step the next out launch finishes
+    int pad;
+    float* x;              // [B][T][D] the chain's sample, updated in place
+    const float* noise;    // [n_steps][B][T][D] injected draws or nullptr
+    const float* prefix;   // [B][prefix_len][D] in-painting source or nullptr
+    uint64_t seed;         // Philox key
+    int64_t window_offset; // global index of window 0 (shard-invariant noise)
+};
+
 // --------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based generator + Box-Muller: four N(0,1) per call.
 struct Philox4 {

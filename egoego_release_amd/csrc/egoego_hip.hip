@@ -51,18 +51,16 @@ struct LayerDev {
     float *b_qkv, *b_fc, *ln1_g, *ln1_b, *b_1, *b_2, *ln2_g, *ln2_b;
 };
 
-// One captured diffusion step (k_step_begin + embed + layers + out).  Everything a kernel of the step receives by
-// value is part of the key; what changes from step to step (t, the step index that selects the injected-noise
-// slice or the DDIM table row) lives in device memory (Workspace::state), so ONE graph serves every step of a chain.
+// One captured diffusion step (embed + layers + out).  Everything a kernel of the step receives by value is part of
+// the key; what changes from step to step (the step index that selects the timestep, the injected-noise slice or the
+// DDIM table row) and from call to call (the caller's x / noise / prefix buffers, the Philox key) lives in device
+// memory (Workspace::state, a StepState), so ONE graph serves every step of every chain of that shape on that workspace.
 struct StepKey {
-    int B, T, mode, noise_mode, prefix_len, clip, ddim;
-    const void *x, *noise, *prefix, *ws;
-    uint64_t seed;
-    int64_t window_offset;
+    int B, T, mode, noise_mode, prefix_len, clip, ddim, has_mask;
+    const void* ws;
     bool operator==(const StepKey& o) const {
         return B == o.B && T == o.T && mode == o.mode && noise_mode == o.noise_mode && prefix_len == o.prefix_len && clip == o.clip &&
-               ddim == o.ddim && x == o.x && noise == o.noise && prefix == o.prefix && ws == o.ws && seed == o.seed &&
-               window_offset == o.window_offset;
+               ddim == o.ddim && has_mask == o.has_mask && ws == o.ws;
     }
 };
 struct StepGraph {
@@ -84,8 +82,12 @@ struct egoego_ctx {
     // hipGraph replay of the per-step launch sequence (egoego_sample_loop / egoego_ddim_loop)
     hipStream_t cap_stream;
     std::vector<StepGraph> graphs;
-    std::vector<int> ddim_ts_host;
-    std::vector<float> ddim_abar_host;
+    // pinned staging slots for the strided sampler's per-step tables (egoego_ddim_loop): a slot is reused only after the
+    // copy that last read it has completed (its event), so the upload never makes the call wait for the stream
+    static const int N_STAGE = 4;
+    void* stage[N_STAGE];
+    hipEvent_t stage_ev[N_STAGE];
+    int stage_next;
     // profiling
     int prof_id;
     std::vector<hipEvent_t> prof_events;
@@ -123,9 +125,9 @@ static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g) {
 }
 
 struct Workspace {
-    int* state;       // [4]: {steps begun, t of the first step} — device-resident so a captured step replays for any t
+    StepState* state; // device-resident step state (common.h): a captured step replays for any t and any caller buffer
     int* step_ts;     // [S] explicit timestep list (DDIM)
-    float* step_abar; // [S] alphas_cumprod of the NEXT list entry (DDIM)
+    float* step_tab;  // [S][4] per-step DDIM coefficients: sqrt(abar_prev), dir, sig, -
     int* t_idx;
     float* row_mask;
     __bf16 *xall, *hA, *hB, *F, *Q, *K, *V, *O;
@@ -143,9 +145,9 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
         off += align_up(bytes, 256);
         return p;
     };
-    w.state = (int*)take(sizeof(int) * 4);
+    w.state = (StepState*)take(sizeof(StepState));
     w.step_ts = (int*)take(sizeof(int) * c->S);
-    w.step_abar = (float*)take(sizeof(float) * c->S);
+    w.step_tab = (float*)take(sizeof(float) * 4 * c->S);
     w.t_idx = (int*)take(sizeof(int) * g.B);
     w.row_mask = (float*)take(sizeof(float) * g.Mp);
     w.xall_plane = (size_t)g.Mp * c->KE;
@@ -400,6 +402,8 @@ static int launch_attn_core8(const AttnCore8Args& a, int KT, int BH, hipStream_t
 
 // ------------------------------------------------------------------------------------ the step
 struct StepIO {
+    StepState* state;       // multi-step loops: the device-resident step state (nullptr: single step, timesteps from t_idx)
+    const int* ts;          // explicit timestep list of a strided sampler or nullptr
     const float* row_mask;  // packed [Mp] or nullptr
     int stop_layer, stop_stage;  // debug early exit (-1: run everything)
     bool run_out;
@@ -419,26 +423,29 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
     const bool small_ln = tb_b < 200;  // below ~400 64-token blocks three separate kernels beat the fused tail (split-bf16 precision; measured B = 32..192)
     const bool direct_io = rows / 64 <= 256;  // embed / linear_out on the direct-operand kernels up to 128 windows of 128 rows (measured: B=128 40 / 38 us against 50 / 55 on the ring kernels, B=256 80 / 72 against 67 / 69)
+    // embed_kernel's chunking (DirectGemm REM2: chunks of 8 k-blocks + a last chunk of 2) fits d_feats = 198's 26 k-blocks;
+    // any other operand width stays on the ring kernels, which take every K
+    const bool direct_embed = direct_io && (c->KE / 16) % 8 == 2;
     // --- embed: start_conv + time token + position embedding (TM:199-216)
-    // i8x3: windows of 97..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
+    // i8x3: windows of 65..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
     // layer reads the embed output as int8 rows
     const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;  // every layer input also as int8 rows
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
-        if (NP == 2 && direct_io) {
+        if (NP == 2 && direct_embed) {
             // small grids: weights streamed into registers, activations by LDS-DMA chunks (tail_fused.h), same arithmetic
             EmbedArgs ea{w.xall, w.xall_plane, c->KE / 16, c->w_embed, (size_t)N_MODEL * c->KE,
                          EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, i8_path ? w.hA8 : nullptr,
-                                           w.h_plane, i8_path ? w.hA_scale : nullptr}};
+                                           w.h_plane, i8_path ? w.hA_scale : nullptr, io.state, io.ts}};
             if (int r = launch_embed_tt<1>(ea, rows, s)) return r;
         } else if (i8_path) {
             // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
-            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale};
+            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
             if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
         } else {
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
-            EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, nullptr, 0, nullptr};
+            EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, nullptr, 0, nullptr, io.state, io.ts};
             if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
         }
     }
@@ -739,6 +746,11 @@ int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
     c->prof_id = -1;
     c->w_embed = c->w_out = nullptr;
     c->cap_stream = nullptr;
+    c->stage_next = 0;
+    for (int i = 0; i < egoego_ctx::N_STAGE; ++i) {
+        c->stage[i] = nullptr;
+        c->stage_ev[i] = nullptr;
+    }
     *out = c;
     return 0;
 }
@@ -756,6 +768,13 @@ void egoego_ctx_destroy(egoego_ctx* c) {
     (void)hipSetDevice(c->device);
     drop_graphs(c);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    for (int i = 0; i < egoego_ctx::N_STAGE; ++i) {
+        if (c->stage_ev[i]) {
+            (void)hipEventSynchronize(c->stage_ev[i]);
+            (void)hipEventDestroy(c->stage_ev[i]);
+        }
+        if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+    }
     for (void* p : c->allocs) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     delete c;
@@ -787,10 +806,11 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
     if (!c || !wt || !wt->layers) return fail(EGOEGO_E_INVALID, "null argument");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
-    // (re)loading frees the previous copies after the stream drained
-    drop_graphs(c);  // captured steps hold the old weight pointers
+    // (re)loading frees the previous copies after the stream drained; captured steps hold the old weight pointers and may
+    // still be executing on it
+    if (c->have_weights || !c->graphs.empty()) HIP_TRY(hipStreamSynchronize(s));
+    drop_graphs(c);
     if (c->have_weights) {
-        HIP_TRY(hipStreamSynchronize(s));
         for (void* p : c->allocs) (void)hipFree(p);
         c->allocs.clear();
         c->layers.clear();
@@ -950,18 +970,27 @@ int egoego_p_sample(egoego_ctx* c, float* d_x, const float* d_xc, const int64_t*
 
 // n_steps diffusion steps on `s`.  The first step of a configuration the context has not seen is launched directly
 // (this also sets the kernels' shared-memory attributes); one step is then captured into a hipGraph on the context's
-// own capture stream (nothing executes there) and the remaining steps are replays of that graph: 11 launches per
-// step become one hipGraphLaunch, which is what keeps small batches (latency-bound kernels) fed.
-static int run_steps(egoego_ctx* c, const Geometry& g, const Workspace& w, StepIO& io, const StepKey& key, int t_start,
+// own capture stream (nothing executes there) and the remaining steps are replays of that graph: 10 launches per
+// step become one hipGraphLaunch.  The caller's buffers and the Philox key reach the kernels through the device-resident
+// StepState, so the captured step serves every later call of the same shape on the same workspace.
+struct StepCall {
+    int t_start;
+    float* x;
+    const float* noise;
+    const float* prefix;
+    uint64_t seed;
+    int64_t window_offset;
+};
+
+static int run_steps(egoego_ctx* c, const Geometry& g, const Workspace& w, StepIO& io, const StepKey& key, const StepCall& call,
                      int n_steps, hipStream_t s) {
-    k_state_init<<<1, 1, 0, s>>>(w.state, t_start);
+    k_state_init<<<1, 1, 0, s>>>(w.state, call.t_start, call.x, call.noise, call.prefix, call.seed, call.window_offset);
     HIP_TRY(hipGetLastError());
-    const int* ts = key.ddim ? w.step_ts : nullptr;
-    auto one_step = [&](hipStream_t st) -> int {
-        k_step_begin<<<1, 256, 0, st>>>(w.state, ts, w.t_idx, g.B);
-        HIP_TRY(hipGetLastError());
-        return run_denoiser(c, g, w, io, st);
-    };
+    io.state = w.state;
+    io.ts = key.ddim ? w.step_ts : nullptr;
+    io.out.state = w.state;
+    io.out.ts = io.ts;
+    auto one_step = [&](hipStream_t st) -> int { return run_denoiser(c, g, w, io, st); };
     const bool graphs = !(c->cfg.flags & EGOEGO_FLAG_NO_GRAPH) && c->prof_id < 0;
     int i = 0;
     if (graphs && n_steps >= 2) {
@@ -977,10 +1006,19 @@ static int run_steps(egoego_ctx* c, const Geometry& g, const Workspace& w, StepI
             HIP_TRY(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed));
             const int r = one_step(c->cap_stream);
             const hipError_t ce = hipStreamEndCapture(c->cap_stream, &e.graph);
-            if (r) return r;
-            if (ce != hipSuccess) return fail(EGOEGO_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-            HIP_TRY(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+            if (r || ce != hipSuccess) {
+                if (ce == hipSuccess && e.graph) (void)hipGraphDestroy(e.graph);
+                return r ? r : fail(EGOEGO_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            }
+            const hipError_t ie = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+            if (ie != hipSuccess) {
+                (void)hipGraphDestroy(e.graph);
+                return fail(EGOEGO_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+            }
             if (c->graphs.size() >= 8) {
+                // the evicted graph may still be executing on a caller stream: drain this one before destroying it
+                // (rare: the ninth distinct step shape of a context)
+                HIP_TRY(hipStreamSynchronize(s));
                 (void)hipGraphExecDestroy(c->graphs.front().exec);
                 (void)hipGraphDestroy(c->graphs.front().graph);
                 c->graphs.erase(c->graphs.begin());
@@ -998,7 +1036,7 @@ static int run_steps(egoego_ctx* c, const Geometry& g, const Workspace& w, StepI
 
 int egoego_sample_loop(egoego_ctx* c, float* d_x, const float* d_xc, int t_start, int n_steps, const float* d_noise,
                        int noise_mode, uint64_t seed, int64_t window_offset, const float* d_prefix, int prefix_len,
-                       int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
+                       const float* d_row_mask, int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
     if (int r = check_ready(c, true)) return r;
     if (!d_x || !d_xc) return fail(EGOEGO_E_INVALID, "null tensor pointer");
     if (t_start < 0 || t_start >= c->S || n_steps < 0 || n_steps > t_start + 1)
@@ -1014,28 +1052,27 @@ int egoego_sample_loop(egoego_ctx* c, float* d_x, const float* d_xc, int t_start
     if (n_steps == 0) return 0;
     StepIO io{};
     // x and x_cond are split/packed ONCE; afterwards the posterior epilogue keeps the embed operand current.
-    if (int r = pack_inputs(c, g, w, d_x, d_xc, nullptr, &io.row_mask, s)) return r;
+    if (int r = pack_inputs(c, g, w, d_x, d_xc, d_row_mask, &io.row_mask, s)) return r;
     io.stop_layer = io.stop_stage = -1;
     io.run_out = true;
     base_out_params(c, g, w, io.out);
     io.out.mode = 1;
-    io.out.x = d_x;
     io.out.noise_mode = noise_mode;
-    io.out.noise = (noise_mode == EGOEGO_NOISE_INJECTED) ? d_noise : nullptr;
-    io.out.seed = seed;
-    io.out.window_offset = window_offset;
-    io.out.prefix = d_prefix;
     io.out.prefix_len = d_prefix ? prefix_len : 0;
-    io.out.state = w.state;
     io.out.step_elems = (size_t)B * T * c->D;
-    const StepKey key{B, T, 1, noise_mode, io.out.prefix_len, 1, 0, d_x, io.out.noise, d_prefix, d_ws, seed, window_offset};
-    return run_steps(c, g, w, io, key, t_start, n_steps, s);
+    const StepKey key{B, T, 1, noise_mode, io.out.prefix_len, 1, 0, d_row_mask ? 1 : 0, d_ws};
+    const StepCall call{t_start, d_x, noise_mode == EGOEGO_NOISE_INJECTED ? d_noise : nullptr, d_prefix, seed, window_offset};
+    return run_steps(c, g, w, io, key, call, n_steps, s);
 }
 
-int egoego_ddim_loop(egoego_ctx* c, float* d_x, const float* d_xc, const int32_t* ts, int n, int B, int T, void* d_ws,
-                     size_t ws_bytes, void* stream) {
+int egoego_ddim_loop(egoego_ctx* c, float* d_x, const float* d_xc, const int32_t* ts, int n, float eta, const float* d_noise,
+                     int noise_mode, uint64_t seed, int64_t window_offset, int B, int T, void* d_ws, size_t ws_bytes, void* stream) {
     if (int r = check_ready(c, true)) return r;
-    if (!d_x || !d_xc || !ts || n < 1) return fail(EGOEGO_E_INVALID, "bad argument");
+    if (!d_x || !d_xc || !ts || n < 1 || n > c->S) return fail(EGOEGO_E_INVALID, "bad argument");
+    if (!(eta >= 0.f && eta <= 1.f)) return fail(EGOEGO_E_INVALID, "eta must be in [0, 1], got %g", (double)eta);
+    if (noise_mode < 0 || noise_mode > 2) return fail(EGOEGO_E_INVALID, "unknown noise_mode %d", noise_mode);
+    if (noise_mode == EGOEGO_NOISE_INJECTED && !d_noise) return fail(EGOEGO_E_INVALID, "noise_mode INJECTED needs d_noise");
+    if (eta > 0.f && noise_mode == EGOEGO_NOISE_NONE) return fail(EGOEGO_E_INVALID, "eta > 0 needs a noise source (INJECTED or PHILOX)");
     for (int i = 0; i < n; ++i)
         if (ts[i] < 0 || ts[i] >= c->S || (i && ts[i] >= ts[i - 1]))
             return fail(EGOEGO_E_INVALID, "DDIM timesteps must be strictly descending in [0, %d)", c->S);
@@ -1046,22 +1083,46 @@ int egoego_ddim_loop(egoego_ctx* c, float* d_x, const float* d_xc, const int32_t
     if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
     StepIO io{};
     if (int r = pack_inputs(c, g, w, d_x, d_xc, nullptr, &io.row_mask, s)) return r;
-    // the timestep list and alphas_cumprod of each step's successor, read by the step kernels through the step index
-    HIP_TRY(hipStreamSynchronize(s));  // the staging vectors below may still feed a previous call's copies
-    c->ddim_ts_host.assign(ts, ts + n);
-    c->ddim_abar_host.resize(n);
-    for (int i = 0; i < n; ++i) c->ddim_abar_host[i] = (i + 1 < n) ? c->abar_host[ts[i + 1]] : 1.0f;
-    HIP_TRY(hipMemcpyAsync(w.step_ts, c->ddim_ts_host.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(w.step_abar, c->ddim_abar_host.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
+    // The timestep list and each step's coefficients (Song et al. 2021, eq. 12 / 16), read by the step kernels through
+    // the step index:  sig = eta sqrt((1 - abar_prev) / (1 - abar_t)) sqrt(1 - abar_t / abar_prev),
+    // x <- sqrt(abar_prev) x0 + sqrt(1 - abar_prev - sig^2) eps + sig z;  abar_prev = 1 after the last entry.
+    // Staged in a pinned slot that is only reused once the copy that read it has finished: no stream synchronisation.
+    {
+        const int slot = c->stage_next;
+        c->stage_next = (slot + 1) % egoego_ctx::N_STAGE;
+        const size_t bytes = (size_t)c->S * (sizeof(int) + 4 * sizeof(float));
+        if (!c->stage[slot]) {
+            HIP_TRY(hipHostMalloc(&c->stage[slot], bytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[slot], hipEventDisableTiming));
+        } else {
+            HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
+        }
+        int* h_ts = (int*)c->stage[slot];
+        float* h_tab = (float*)(h_ts + c->S);
+        for (int i = 0; i < n; ++i) {
+            const double at = c->abar_host[ts[i]], ap = (i + 1 < n) ? (double)c->abar_host[ts[i + 1]] : 1.0;
+            double sig = 0.0;
+            if (eta > 0.f && ap < 1.0 && at < 1.0) sig = (double)eta * sqrt((1.0 - ap) / (1.0 - at)) * sqrt(fmax(1.0 - at / ap, 0.0));
+            h_ts[i] = ts[i];
+            h_tab[4 * i + 0] = (float)sqrt(ap);
+            h_tab[4 * i + 1] = (float)sqrt(fmax(1.0 - ap - sig * sig, 0.0));
+            h_tab[4 * i + 2] = (float)sig;
+            h_tab[4 * i + 3] = 0.f;
+        }
+        HIP_TRY(hipMemcpyAsync(w.step_ts, h_ts, sizeof(int) * n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w.step_tab, h_tab, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(c->stage_ev[slot], s));
+    }
     io.stop_layer = io.stop_stage = -1;
     io.run_out = true;
     base_out_params(c, g, w, io.out);
     io.out.mode = 2;
-    io.out.x = d_x;
-    io.out.state = w.state;
-    io.out.abar_prev_tab = w.step_abar;
-    const StepKey key{B, T, 2, EGOEGO_NOISE_NONE, 0, 1, 1, d_x, nullptr, nullptr, d_ws, 0, 0};
-    return run_steps(c, g, w, io, key, 0, n, s);
+    io.out.noise_mode = eta > 0.f ? noise_mode : EGOEGO_NOISE_NONE;
+    io.out.ddim_tab = w.step_tab;
+    io.out.step_elems = (size_t)B * T * c->D;
+    const StepKey key{B, T, 2, io.out.noise_mode, 0, 1, 1, 0, d_ws};
+    const StepCall call{0, d_x, io.out.noise_mode == EGOEGO_NOISE_INJECTED ? d_noise : nullptr, nullptr, seed, window_offset};
+    return run_steps(c, g, w, io, key, call, n, s);
 }
 
 int egoego_rot6d_to_matrix(const float* d_in, float* d_out, int64_t n, void* stream) {

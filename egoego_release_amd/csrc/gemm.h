@@ -712,17 +712,28 @@ struct EpiEmbed {
     int8_t* q8;
     size_t q8_plane;
     float* q8_scale;
+    // multi-step loops (nullptr: single step, timesteps from t_idx): the step state of pointwise.h — every window runs
+    // the timestep of step state->embed_step; this kernel then publishes embed_step + 1 as the out kernel's counter
+    StepState* state;
+    const int* ts;          // explicit timestep list (strided samplers) or nullptr: t = t_start - step
     template <int FT, int TT>
     __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem) const {
         const int hf = lane >> 5, col = lane & 31;
         constexpr bool Q8 = NWF > 0 && NWF * FT * 32 == 512;
         float* red = (float*)smem;  // [TT][NWF][BT] row maxima per wave (Q8 only)
+        int t_loop = 0;
+        if (state) {
+            const int i = state->embed_step;
+            t_loop = ts ? ts[i] : state->t_start - i;
+            // no block of THIS launch reads out_step; the step's out kernel (a later launch on the stream) does
+            if (blockIdx.x == 0 && threadIdx.x == 0) state->out_step = i + 1;
+        }
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
             const int b = m / Lp, lw = m % Lp;
             const int kind = (b >= B || lw > T) ? 0 : (lw == 0 ? 1 : 2);
-            const float* trow = (kind == 1) ? tt_table + (size_t)t_idx[b] * 512 : nullptr;
+            const float* trow = (kind == 1) ? tt_table + (size_t)(state ? t_loop : t_idx[b]) * 512 : nullptr;
             const float* prow = (kind == 2) ? pe + (size_t)(lw + 1) * 512 : nullptr;
             float amax = 0.f;
 #pragma unroll
@@ -792,29 +803,42 @@ struct EpiEmbed {
 // re-split of the new x into the embed GEMM's operand for the next step.
 struct OutParams {
     const float* bias;     // [256] zero padded
-    int mode;              // 0: raw model output -> out_raw; 1: posterior update of x
-    float* x;              // [B][T][D] in/out (mode 1)
+    int mode;              // 0: raw model output -> out_raw; 1: posterior update of x; 2: DDIM update of x
+    float* x;              // [B][T][D] in/out (modes 1, 2; single step — loops take it from the step state)
     float* out_raw;        // [B][T][D] (mode 0)
     __bf16* xall;          // fragment-tiled [Mp][KE]
     size_t xall_plane;
     int KE16;
     const float* sched;    // [S][8]: c1, c2, sigma, sqrt_recip, sqrt_recipm1, abar, -, -
     const int* t_idx;      // [B]
-    const float* noise;    // [B][T][D] or nullptr
+    const float* noise;    // [B][T][D] or nullptr (single step)
     int noise_mode;        // EGOEGO_NOISE_*
-    uint64_t seed;
-    int64_t window_offset;
+    uint64_t seed;         // (single step)
+    int64_t window_offset; // (single step)
     int clip;
     int objective;         // 1 = pred_x0
-    const float* prefix;   // [B][prefix_len][D] or nullptr
-    int prefix_len;
-    // DDIM (mode 2): x <- sqrt(abar_prev) * x0 + sqrt(1 - abar_prev) * eps
-    const float* abar_prev_tab;  // [n] alphas_cumprod of each step's successor, indexed by the step index
-    // multi-step loops: state[0] - 1 is the index of the running step (device-resident so that one captured step
-    // replays for the whole chain); it selects the injected-noise slice and the DDIM table row.  nullptr: single step.
-    const int* state;
+    const float* prefix;   // [B][prefix_len][D] or nullptr (single step: never set)
+    int prefix_len;        // > 0: in-paint the first frames of every window from the step state's prefix after the update
+    // DDIM (mode 2): x <- sqrt(abar_prev) * x0 + dir * eps + sig * z, per-step coefficients indexed by the step index
+    const float* ddim_tab;  // [n][4]: sqrt(abar_prev), dir = sqrt(1 - abar_prev - sig^2), sig, -
+    // multi-step loops: everything that changes from call to call or from step to step lives in device memory (the
+    // step state, pointwise.h), so that ONE captured step replays for every timestep, every chain and every caller
+    // buffer: state->out_step - 1 is the index of the running step (selects the timestep, the injected-noise slice
+    // and the DDIM table row); x / noise / prefix / seed / window_offset come from it too.  nullptr: single step.
+    StepState* state;
+    const int* ts;         // explicit timestep list or nullptr
     size_t step_elems;     // B*T*D: stride between the injected-noise slices of consecutive steps
     int Lp, T, B, D, DP;
+};
+
+// what a launch of the out kernel reads from the step state (or, for a single step, from OutParams)
+struct OutDyn {
+    float* x;
+    const float* noise;
+    const float* prefix;
+    uint64_t seed;
+    int64_t window_offset;
+    float a_prev, dir, sig;  // DDIM coefficients of this step
 };
 
 template <int NP>
@@ -822,7 +846,7 @@ struct EpiOut {
     OutParams p;
     // one group = 4 consecutive features f..f+3 of one frame
     __device__ void group(const float (&o)[4], int f, int m, int b, int frame, size_t row, int t, float c1, float c2,
-                          float sigma, float srec, float srecm1, float abar, const float* noise, float abar_prev) const {
+                          float sigma, float srec, float srecm1, float abar, const OutDyn& d) const {
         if (p.mode == 0) {
 #pragma unroll
             for (int c = 0; c < 4; c += 2)
@@ -833,21 +857,21 @@ struct EpiOut {
 #pragma unroll
         for (int c = 0; c < 4; c += 2)
             if (f + c < p.D) {
-                const float2 v = *(const float2*)(p.x + row + f + c);
+                const float2 v = *(const float2*)(d.x + row + f + c);
                 xt[c] = v.x;
                 xt[c + 1] = v.y;
             }
-        if (p.mode == 1 && sigma != 0.f) {
+        if (sigma != 0.f) {  // the step's noise scale: ancestral sigma_t (mode 1) or the DDIM sig (mode 2, eta > 0)
             if (p.noise_mode == 0) {
 #pragma unroll
                 for (int c = 0; c < 4; c += 2)
                     if (f + c < p.D) {
-                        const float2 v = *(const float2*)(noise + row + f + c);
+                        const float2 v = *(const float2*)(d.noise + row + f + c);
                         nz[c] = v.x;
                         nz[c + 1] = v.y;
                     }
             } else if (p.noise_mode == 1) {
-                philox_normal4(p.seed, (uint32_t)(f >> 2), (uint32_t)frame, (uint32_t)(p.window_offset + b), (uint32_t)t, nz);
+                philox_normal4(d.seed, (uint32_t)(f >> 2), (uint32_t)frame, (uint32_t)(d.window_offset + b), (uint32_t)t, nz);
             }
         }
         float xn[4];
@@ -858,21 +882,21 @@ struct EpiOut {
             if (p.mode == 1) {
                 const float mean = c1 * x0 + c2 * xt[c];
                 xn[c] = mean + sigma * nz[c];
-            } else {  // DDIM, eta = 0
+            } else {  // DDIM (Song et al. 2021, eq. 12): predicted noise from x0, then the eta-weighted step
                 const float eps = (xt[c] - sqrtf(abar) * x0) / sqrtf(fmaxf(1.0f - abar, 1e-20f));
-                xn[c] = sqrtf(abar_prev) * x0 + sqrtf(fmaxf(1.0f - abar_prev, 0.f)) * eps;
+                xn[c] = d.a_prev * x0 + d.dir * eps + sigma * nz[c];
             }
             if (f + c >= p.D) xn[c] = 0.f;
         }
-        if (p.prefix && frame < p.prefix_len) {
-            const float* pr = p.prefix + ((size_t)b * p.prefix_len + frame) * p.D;
+        if (d.prefix && frame < p.prefix_len) {
+            const float* pr = d.prefix + ((size_t)b * p.prefix_len + frame) * p.D;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (f + c < p.D) xn[c] = pr[f + c];
         }
 #pragma unroll
         for (int c = 0; c < 4; c += 2)
-            if (f + c < p.D) *(float2*)(p.x + row + f + c) = make_float2(xn[c], xn[c + 1]);
+            if (f + c < p.D) *(float2*)(d.x + row + f + c) = make_float2(xn[c], xn[c + 1]);
         uint2 hi, lo;
         split4(xn, hi, lo);
         const size_t idx = tiled_index(m, f, p.KE16);
@@ -883,9 +907,23 @@ struct EpiOut {
     template <int FT, int TT>
     __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
         const int hf = lane >> 5, col = lane & 31;
-        const int step = p.state ? p.state[0] - 1 : 0;
-        const float* noise = p.noise ? p.noise + (size_t)step * p.step_elems : nullptr;
-        const float abar_prev = p.abar_prev_tab ? p.abar_prev_tab[step] : 1.0f;
+        OutDyn d{p.x, p.noise, p.prefix, p.seed, p.window_offset, 1.0f, 0.f, 0.f};
+        int step = 0, t_loop = 0;
+        if (p.state) {
+            step = p.state->out_step - 1;
+            t_loop = p.ts ? p.ts[step] : p.state->t_start - step;
+            d.x = p.state->x;
+            d.noise = p.state->noise ? p.state->noise + (size_t)step * p.step_elems : nullptr;
+            d.prefix = p.prefix_len ? p.state->prefix : nullptr;
+            d.seed = p.state->seed;
+            d.window_offset = p.state->window_offset;
+            // no block of THIS launch reads embed_step; the next step's embed kernel does
+            if (blockIdx.x == 0 && threadIdx.x == 0) p.state->embed_step = step + 1;
+        }
+        if (p.ddim_tab) {
+            const float4 dd = *(const float4*)(p.ddim_tab + 4 * step);
+            d.a_prev = dd.x; d.dir = dd.y; d.sig = dd.z;
+        }
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
@@ -896,9 +934,9 @@ struct EpiOut {
             float c1 = 0.f, c2 = 0.f, sigma = 0.f, srec = 0.f, srecm1 = 0.f, abar = 0.f;
             int t = 0;
             if (valid && p.mode != 0) {
-                t = p.t_idx[b];
+                t = p.state ? t_loop : p.t_idx[b];
                 const float* s = p.sched + (size_t)t * 8;
-                c1 = s[0]; c2 = s[1]; sigma = s[2]; srec = s[3]; srecm1 = s[4]; abar = s[5];
+                c1 = s[0]; c2 = s[1]; sigma = p.mode == 2 ? d.sig : s[2]; srec = s[3]; srecm1 = s[4]; abar = s[5];
             }
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -909,7 +947,7 @@ struct EpiOut {
                         const float4 b4 = *(const float4*)(p.bias + f);
                         const float o[4] = {acc[i][j][4 * g + 0] + b4.x, acc[i][j][4 * g + 1] + b4.y,
                                             acc[i][j][4 * g + 2] + b4.z, acc[i][j][4 * g + 3] + b4.w};
-                        group(o, f, m, b, frame, row, t, c1, c2, sigma, srec, srecm1, abar, noise, abar_prev);
+                        group(o, f, m, b, frame, row, t, c1, c2, sigma, srec, srecm1, abar, d);
                     }
                 }
         }

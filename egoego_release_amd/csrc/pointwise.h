@@ -122,24 +122,18 @@ __global__ void k_convert_t(const int64_t* __restrict__ t, int* __restrict__ out
     }
 }
 
-// Step state of a multi-step loop, kept in device memory so that ONE captured step (hipGraph) replays for every
-// timestep: state[0] = steps begun, state[1] = timestep of the first step.  k_step_begin (one block) publishes the
-// current step's timestep for every window — t_start - i for the ancestral chain (M:267-268), ts[i] for a strided
-// list — and advances the counter; the step's kernels read state[0] - 1 as the index of the running step.
-__global__ void k_state_init(int* __restrict__ state, int t_start) {
-    state[0] = 0;
-    state[1] = t_start;
-}
-
-__global__ __launch_bounds__(256) void k_step_begin(int* __restrict__ state, const int* __restrict__ ts, int* __restrict__ t_idx, int B) {
-    __shared__ int t_sh;
-    if (threadIdx.x == 0) {
-        const int i = state[0];
-        t_sh = ts ? ts[i] : state[1] - i;
-        state[0] = i + 1;
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += 256) t_idx[b] = t_sh;
+// (Re)arm the step state (gemm.h StepState) at the start of a multi-step call: one thread.
+__global__ void k_state_init(StepState* __restrict__ st, int t_start, float* x, const float* noise, const float* prefix, uint64_t seed,
+                             int64_t window_offset) {
+    st->embed_step = 0;
+    st->t_start = t_start;
+    st->out_step = 0;
+    st->pad = 0;
+    st->x = x;
+    st->noise = noise;
+    st->prefix = prefix;
+    st->seed = seed;
+    st->window_offset = window_offset;
 }
 
 // Padding mask [B][T+1] -> one multiplier per padded token row.

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void embed_kernel(EmbedArgs a) {
     f32x16 acc[4][TT];
     G::run(acc, a.x, a.x_plane, a.K16, a.w, a.w_plane, smem, (int)blockIdx.x * TT, wave, lane, [] {});
     const EpiEmbed<2, 4, 32 * TT> e{a.epi.bias, a.epi.pe, a.epi.tt_table, a.epi.t_idx, a.epi.out, a.epi.out_plane, a.epi.Lp, a.epi.T, a.epi.B,
-                                    a.epi.q8, a.epi.q8_plane, a.epi.q8_scale};
+                                    a.epi.q8, a.epi.q8_plane, a.epi.q8_scale, a.epi.state, a.epi.ts};
     e.template run<4, TT>(acc, wave * 128, (int)blockIdx.x * 32 * TT, lane, wave, 0, smem);
 }
 

@@ -143,8 +143,9 @@ class HipEngine:
         return x
 
     def sample_loop_(self, x, x_cond, t_start, n_steps, noise=None, noise_mode=None, seed=0, window_offset=0,
-                     prefix=None):
-        """In-place: n_steps ancestral steps from timestep t_start downwards."""
+                     prefix=None, row_mask=None):
+        """In-place: n_steps ancestral steps from timestep t_start downwards (row_mask: the padding mask every
+        step's denoiser pass applies, [B, 1, T+1] / [B, T+1])."""
         B, T, D = x.shape
         if noise_mode is None:
             noise_mode = _lib.NOISE_INJECTED if noise is not None else _lib.NOISE_PHILOX
@@ -154,17 +155,22 @@ class HipEngine:
         if prefix is not None:
             plen = prefix.shape[1]
             pp = self._chk(prefix, (B, plen, D))
+        m, mp = self._mask(row_mask, B, T)
         _lib.check(self.lib.egoego_sample_loop(self._ctx, self._chk(x), self._chk(x_cond, x.shape), t_start, n_steps,
-                                               npnt, noise_mode, seed, window_offset, pp, plen, B, T, ws, n,
+                                               npnt, noise_mode, seed, window_offset, pp, plen, mp, B, T, ws, n,
                                                self._stream()))
         return x
 
-    def ddim_loop_(self, x, x_cond, timesteps):
+    def ddim_loop_(self, x, x_cond, timesteps, eta=0.0, noise=None, noise_mode=None, seed=0, window_offset=0):
+        """In-place DDIM over the descending `timesteps`; eta > 0 adds eta-weighted noise (injected [n, B, T, D] or Philox)."""
         B, T, D = x.shape
         ws, n = self.workspace(B, T)
         arr = (C.c_int32 * len(timesteps))(*[int(v) for v in timesteps])
+        if noise_mode is None:
+            noise_mode = _lib.NOISE_INJECTED if noise is not None else (_lib.NOISE_PHILOX if eta > 0 else _lib.NOISE_NONE)
+        npnt = self._chk(noise, (len(timesteps), B, T, D)) if noise is not None else None
         _lib.check(self.lib.egoego_ddim_loop(self._ctx, self._chk(x), self._chk(x_cond, x.shape), arr, len(timesteps),
-                                             B, T, ws, n, self._stream()))
+                                             float(eta), npnt, noise_mode, seed, window_offset, B, T, ws, n, self._stream()))
         return x
 
     def debug_stage(self, x, x_cond, t, layer, stage, row_mask=None):

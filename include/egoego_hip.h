@@ -11,8 +11,21 @@
  * Conventions
  *   - every pointer named d_* is a DEVICE pointer owned by the caller (PyTorch allocates all I/O
  *     tensors and the workspace); the library never frees or retains caller memory except the
- *     workspace during a call, never synchronises the stream, and launches only on `stream`
- *     (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *     workspace during a call, and launches only on `stream` (a hipStream_t passed as void*;
+ *     NULL = the legacy default stream).
+ *   - synchronisation: the SAMPLING entry points (egoego_denoise, _p_sample, _sample_loop, _ddim_loop,
+ *     _rot6d_to_matrix, _convert_model_res, _window_condition, _window_prefix, _debug_stage) only enqueue
+ *     work and return; they never wait for the stream.  (egoego_ddim_loop stages its step table in a pinned
+ *     slot and waits, at most, for the copy of the call four calls earlier; egoego_sample_loop drains the stream
+ *     once if a context has seen more than eight distinct step shapes and must evict a captured graph.)
+ *     The SETUP entry points egoego_load_weights and egoego_load_schedule DO call hipStreamSynchronize(stream)
+ *     (host staging buffers; a re-load first waits for work that still reads the old weights), and
+ *     egoego_profile_end waits for its events.
+ *   - `stream` must NOT be in capture mode (torch.cuda.graph / hipStreamBeginCapture by the caller):
+ *     the multi-step loops capture their own per-step hipGraph on a private stream (relaxed mode) and launch
+ *     graphs on `stream`, and the setup calls synchronise.  egoego_denoise / egoego_p_sample are plain kernel
+ *     launches and can be captured by the caller once the context has run that shape (first use sets kernel
+ *     attributes).
  *   - pose tensors are fp32, contiguous, [B][T][d_feats]; timesteps are int64 [B] (torch.long).
  *   - return value: 0 = ok; negative = error (EGOEGO_E_*); egoego_last_error() describes the last
  *     failure on the calling thread.
@@ -28,7 +41,7 @@
 extern "C" {
 #endif
 
-#define EGOEGO_ABI_VERSION 2
+#define EGOEGO_ABI_VERSION 3
 
 enum {
     EGOEGO_OK = 0,
@@ -134,22 +147,27 @@ int egoego_p_sample(egoego_ctx* ctx, float* d_x, const float* d_x_cond, const in
                     void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Replaces the body of p_sample_loop (M:267-268) and of the sliding-window loop (M:392-397):
- * for i = t_start .. t_start-n_steps+1: x <- p_sample(x, i, x_cond); optionally overwrite the first
+ * for i = t_start .. t_start-n_steps+1: x <- p_sample(x, i, x_cond, padding_mask); optionally overwrite the first
  * prefix_len frames of every window with d_prefix[B][prefix_len][D] after every step (M:395-397).
+ * d_row_mask: the padding mask p_sample_loop hands to every step (M:259,268), fp32 [B][T+1] as for
+ * egoego_denoise, or NULL.
  * Noise per step: EGOEGO_NOISE_INJECTED reads d_noise[step][B][T][D] (step 0 = first executed
  * step); EGOEGO_NOISE_PHILOX draws N(0,1) in-kernel from Philox4x32-10 keyed by
  * (seed; window_offset + b, timestep, frame, feature) so results do not depend on how windows are
  * sharded over GPUs. */
 int egoego_sample_loop(egoego_ctx* ctx, float* d_x, const float* d_x_cond, int t_start, int n_steps,
                        const float* d_noise, int noise_mode, uint64_t seed, int64_t window_offset,
-                       const float* d_prefix, int prefix_len, int B, int T,
+                       const float* d_prefix, int prefix_len, const float* d_row_mask, int B, int T,
                        void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* Deterministic DDIM sampler (eta = 0) on a strided subsequence of timesteps.  NOT in the
- * reference — no oracle from the reference exists for it.  d_timesteps_host:
- * HOST int32 array of n descending timesteps. */
-int egoego_ddim_loop(egoego_ctx* ctx, float* d_x, const float* d_x_cond, const int32_t* timesteps_host,
-                     int n, int B, int T, void* d_workspace, size_t workspace_bytes, void* stream);
+/* DDIM sampler (Song et al. 2021) on a strided subsequence of timesteps.  NOT in the reference —
+ * no oracle from the reference exists for it.  timesteps_host: HOST int32 array of n strictly descending timesteps.
+ * eta in [0, 1]: 0 = deterministic; 1 on the FULL timestep list is the ancestral DDPM chain of egoego_sample_loop
+ * (sigma_t^2 = posterior variance), which is how the sampler is tied to the reference's chain (tests).  Noise for
+ * eta > 0 as for egoego_sample_loop (d_noise[step][B][T][D] or Philox keyed by (seed; window_offset + b, timestep, ..)). */
+int egoego_ddim_loop(egoego_ctx* ctx, float* d_x, const float* d_x_cond, const int32_t* timesteps_host, int n,
+                     float eta, const float* d_noise, int noise_mode, uint64_t seed, int64_t window_offset,
+                     int B, int T, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Replaces pytorch3d.transforms.rotation_6d_to_matrix at M:493: d_in [n][6] -> d_out [n][3][3]. */
 int egoego_rot6d_to_matrix(const float* d_in, float* d_out, int64_t n, void* stream);

@@ -243,11 +243,14 @@ def rotation_6d_to_matrix(d6):
 
 
 # --------------------------------------------------------------------------- DDIM (NOT in the reference)
-def ddim_loop(sd, sched, x, x_cond, timesteps, objective="pred_x0"):
-    """Deterministic DDIM (eta = 0; Song et al. 2021 eq. 12) on a descending list of timesteps, with the
-    reference's x0 clamp.  The reference has no DDIM sampler, so this restates the
-    published update rule, not reference code; it is the checker for egoego_ddim_loop only."""
-    abar = sched["alphas_cumprod"]
+def ddim_loop(sd, sched, x, x_cond, timesteps, objective="pred_x0", eta=0.0, noise=None):
+    """DDIM (Song et al. 2021 eq. 12 / 16) on a descending list of timesteps, with the reference's x0 clamp; eta = 0 is
+    deterministic, eta > 0 adds sig_t * noise[i] with sig_t = eta sqrt((1 - abar_prev) / (1 - abar_t)) sqrt(1 - abar_t / abar_prev).
+    The reference has no DDIM sampler, so this restates the published update rule, not reference
+    code; it is the checker for egoego_ddim_loop only.  With eta = 1 on the full list 999..0 the update IS the
+    reference's ancestral step (sig_t^2 = posterior variance, same mean), which test_oracle_golden.py checks against
+    p_sample — the one tie between this sampler and the reference's chain."""
+    abar = sched["alphas_cumprod"].double()
     b = x.shape[0]
     for i, t in enumerate(timesteps):
         tt = torch.full((b,), int(t), dtype=torch.long)
@@ -258,7 +261,12 @@ def ddim_loop(sd, sched, x, x_cond, timesteps, objective="pred_x0"):
             x0 = sched["sqrt_recip_alphas_cumprod"][t] * x - sched["sqrt_recipm1_alphas_cumprod"][t] * out
         x0 = x0.clamp(-1.0, 1.0)
         a_t = abar[t]
-        a_prev = abar[timesteps[i + 1]] if i + 1 < len(timesteps) else torch.tensor(1.0)
-        eps = (x - a_t.sqrt() * x0) / (1 - a_t).clamp(min=1e-20).sqrt()
-        x = a_prev.sqrt() * x0 + (1 - a_prev).clamp(min=0).sqrt() * eps
+        a_prev = abar[timesteps[i + 1]] if i + 1 < len(timesteps) else torch.tensor(1.0, dtype=torch.float64)
+        sig = torch.tensor(0.0, dtype=torch.float64)
+        if eta > 0 and a_prev < 1 and a_t < 1:
+            sig = eta * ((1 - a_prev) / (1 - a_t)).sqrt() * (1 - a_t / a_prev).clamp(min=0).sqrt()
+        eps = (x - a_t.sqrt().float() * x0) / (1 - a_t).float().clamp(min=1e-20).sqrt()
+        x = a_prev.sqrt().float() * x0 + (1 - a_prev - sig * sig).clamp(min=0).sqrt().float() * eps
+        if eta > 0:
+            x = x + sig.float() * noise[i]
     return x

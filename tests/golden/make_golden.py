@@ -153,6 +153,21 @@ def main():
         out[f"sample_{tag}"] = y_ref.numpy()
         print(tag, "ok, absmax", y_ref.abs().max().item())
 
+    # --- p_sample_loop WITH a padding mask (M:259, 268 hand it to every step): B=2, 10 steps
+    cfg, ref, sd, full = build(120)
+    xs, cm = make_head_windows(2, 120, seed=13)
+    pm = torch.ones(2, 1, 121).bool()
+    pm[0, 0, 100:] = False
+    pm[1, 0, 61:] = False
+    ref.num_timesteps = 10
+    torch.manual_seed(321)
+    with torch.no_grad():
+        y_ref = ref.p_sample_loop(xs.shape, xs, cm, padding_mask=pm)
+    y_or = O.p_sample_loop(sd, sched, xs, cm, torch.Generator().manual_seed(321), num_timesteps=10, padding_mask=pm)
+    assert torch.equal(y_ref, y_or), (y_ref - y_or).abs().max()
+    out["sample_padmask_b2_s10"] = y_ref.numpy()
+    print("padmask chain ok, absmax", y_ref.abs().max().item())
+
     path = os.path.join(HERE, "stage2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

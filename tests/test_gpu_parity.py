@@ -241,13 +241,13 @@ def test_ddim_against_oracle_restatement(prec):
 @pytest.mark.parametrize("B,T,n_head,n_layers", [(1, 1, 4, 4), (3, 2, 4, 4), (5, 31, 4, 4), (3, 63, 4, 4), (2, 95, 4, 4), (3, 96, 4, 4), (2, 127, 4, 4),
                                                   (2, 128, 4, 4), (1, 223, 4, 4), (2, 50, 2, 1), (2, 120, 8, 2)])
 def test_shape_edge_cases_against_oracle(B, T, n_head, n_layers, prec):
-    """Minimum window (T=1), every key-tile boundary (L = 32/64/96/97/128/129; 97..128 is the i8x3 kernel's range), the maximum supported window
+    """Minimum window (T=1), every key-tile boundary (L = 32/64/65/96/97/128/129; 65..128 is the one-kernel i8x3 attention layer's range), the maximum supported window
     (T=223), odd batches, and other head / layer counts than the shipped checkpoint's."""
     cfg = ModelConfig(max_timesteps=T + 1, n_head=n_head, n_dec_layers=n_layers)
     sd = make_weights(cfg, 3)
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
     m.load_state_dict(sd, strict=False)
-    m.hip_precision = prec  # i8x3 covers 96 < L <= 128 (one workgroup per window and head); other lengths run split-bf16
+    m.hip_precision = prec  # i8x3: 64 < L <= 128 runs the one-kernel attention layer (one workgroup per window and head), other lengths the int8 projection kernels
     m = m.cuda()
     g = torch.Generator().manual_seed(100 * T + B)
     x_all = torch.randn(B, T, 396, generator=g)
@@ -260,6 +260,31 @@ def test_shape_edge_cases_against_oracle(B, T, n_head, n_layers, prec):
     noise = torch.randn(B, T, 198, generator=g)
     want = O.p_sample(sd, O.make_schedule(1000), x_all[..., :198], t, x_all[..., 198:], noise, n_head=n_head)
     got = m.p_sample(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda(), noise=noise.cuda()).cpu()
+    assert (got - want).abs().max().item() < POSE_TOL
+
+
+@pytest.mark.parametrize("d_feats", [30, 64, 100, 248])
+def test_other_feature_widths_against_oracle(d_feats, prec):
+    """The embed operand has 2 * ceil8(d_feats) columns padded to 32: 26 k-blocks of 16 for the shipped d_feats = 198, which is
+    what the small-batch embed kernel's chunking (8 + 8 + 8 + 2) is built for.  Other widths (4 / 8 / 14 / 32 k-blocks here)
+    must take the general kernels and still match the oracle, at a small batch (where the direct-operand kernels run)."""
+    B, T = 3, 40
+    cfg = ModelConfig(d_feats=d_feats, max_timesteps=T + 1)
+    sd = make_weights(cfg, 5)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m.hip_precision = prec
+    m = m.cuda()
+    g = torch.Generator().manual_seed(d_feats)
+    x_all = torch.randn(B, T, 2 * d_feats, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        want = O.denoise(sd, x_all, t)
+    got = m.denoise(x_all[..., :d_feats].contiguous().cuda(), t.cuda(), x_all[..., d_feats:].contiguous().cuda()).cpu()
+    assert (got - want).abs().max().item() < POSE_TOL
+    noise = torch.randn(B, T, d_feats, generator=g)
+    want = O.p_sample(sd, O.make_schedule(1000), x_all[..., :d_feats], t, x_all[..., d_feats:], noise)
+    got = m.p_sample(x_all[..., :d_feats].contiguous().cuda(), t.cuda(), x_all[..., d_feats:].contiguous().cuda(), noise=noise.cuda()).cpu()
     assert (got - want).abs().max().item() < POSE_TOL
 
 
@@ -384,6 +409,93 @@ def test_graph_replay_equals_individual_launches(prec):
         res[graph] = out[:3]
     for u, v in zip(res[True], res[False]):
         assert torch.equal(u, v)
+
+
+def test_captured_step_serves_other_buffers_and_seeds(prec):
+    """The caller's x / noise / prefix pointers and the Philox key reach the kernels through the device-resident step
+    state, so a step captured for one call replays for calls on OTHER tensors, seeds and window offsets: results must
+    equal those of a fresh engine that never saw the first call, and of the no-graph engine."""
+    B, T, S = 3, 120, 6
+    xs, cm = make_head_windows(B, T, seed=12)
+    g = torch.Generator().manual_seed(16)
+    xa, xb = torch.randn(xs.shape, generator=g).cuda(), torch.randn(xs.shape, generator=g).cuda()
+    xc = (xs * (1 - cm) + cm * torch.randn(xs.shape, generator=g)).cuda()
+    nz1, nz2 = torch.randn(S, B, T, 198, generator=g).cuda(), torch.randn(S, B, T, 198, generator=g).cuda()
+    cfg, sd, m = _model(precision=prec)
+    eng = m.hip_engine()
+    r = []
+    for x0, seed, off, nz in ((xa, 3, 0, nz1), (xb, 11, 64, nz2)):
+        a = x0.clone()
+        eng.sample_loop_(a, xc, 999, S, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=off)
+        b = x0.clone()
+        eng.sample_loop_(b, xc, 500, S, noise=nz.clone())
+        r.append((a, b))
+    cfg, sd, m2 = _model(precision=prec)
+    m2.hip_graph = False
+    e2 = m2.hip_engine()
+    a = xb.clone()
+    e2.sample_loop_(a, xc, 999, S, noise_mode=_lib.NOISE_PHILOX, seed=11, window_offset=64)
+    b = xb.clone()
+    e2.sample_loop_(b, xc, 500, S, noise=nz2)
+    assert torch.equal(r[1][0], a) and torch.equal(r[1][1], b)
+    assert not torch.equal(r[0][0], r[1][0])
+
+
+def test_p_sample_loop_with_padding_mask(golden, prec):
+    """M:259, 268: p_sample_loop(padding_mask=...) masks every step's denoiser pass.  Fixture: the reference's own 10-step
+    chain with its own draws; then the default torch-RNG path must consume the generator like the reference does and run as
+    one HIP loop (same result as feeding the same draws through p_sample step by step)."""
+    cfg, sd, m = _model(precision=prec)
+    m.num_timesteps = 10
+    xs, cm = make_head_windows(2, 120, seed=13)
+    pm = torch.ones(2, 1, 121).bool()
+    pm[0, 0, 100:] = False
+    pm[1, 0, 61:] = False
+    y = m.p_sample_loop(xs.shape, xs.cuda(), cm.cuda(), padding_mask=pm.cuda(), noise=_ref_noise(xs.shape, 10, seed=321)).cpu().numpy()
+    assert np.abs(y - golden["sample_padmask_b2_s10"]).max() < POSE_TOL
+    xs, cm, pm = xs.cuda(), cm.cuda(), pm.cuda()
+    torch.manual_seed(5)
+    got = m.p_sample_loop(xs.shape, xs, cm, padding_mask=pm)
+    torch.manual_seed(5)
+    x = torch.randn(xs.shape, device="cuda")
+    xc = xs * (1.0 - cm) + cm * torch.randn_like(xs)
+    for i in reversed(range(10)):
+        x = m.p_sample(x, torch.full((2,), i, device="cuda", dtype=torch.long), xc, padding_mask=pm)
+    assert torch.equal(got, x)
+    unmasked = m.p_sample_loop(xs.shape, xs, cm, noise=_ref_noise(xs.shape, 10, seed=321))
+    assert np.abs(unmasked.cpu().numpy() - golden["sample_padmask_b2_s10"]).max() > 1e-2  # the mask matters
+
+
+def test_ddim_eta1_full_chain_is_the_ddpm_chain(prec):
+    """SURVEY.md §8f #3's self-consistency check.  DDIM with eta = 1 on ALL timesteps 999..0 is algebraically the
+    reference's ancestral chain (sig_t^2 = posterior variance, DDIM mean = posterior mean), so with the same Philox
+    key it must land on egoego_sample_loop's result up to rounding — the tie between the strided sampler and the
+    chain the reference pins.  Also eta = 0.5 on a 12-step stride against the oracle restatement with injected noise."""
+    cfg, sd, m = _model(precision=prec)
+    eng = m.hip_engine()
+    B, T = 2, 120
+    xs, cm = make_head_windows(B, T, seed=21)
+    g = torch.Generator().manual_seed(22)
+    x0 = torch.randn(xs.shape, generator=g).cuda()
+    xc_cpu = xs * (1 - cm) + cm * torch.randn(xs.shape, generator=g)
+    xc = xc_cpu.cuda()
+    a = x0.clone()
+    eng.sample_loop_(a, xc, 999, 1000, noise_mode=_lib.NOISE_PHILOX, seed=9, window_offset=5)
+    b = x0.clone()
+    eng.ddim_loop_(b, xc, list(range(999, -1, -1)), eta=1.0, seed=9, window_offset=5)
+    assert (a - b).abs().max().item() < 3e-4, (a - b).abs().max().item()
+    c = x0.clone()
+    eng.ddim_loop_(c, xc, list(range(999, -1, -1)), eta=0.0)
+    assert (a - c).abs().max().item() > 1e-2  # eta matters
+    ts = sorted({int(round(v)) for v in np.linspace(0, 999, 12)}, reverse=True)
+    nz = torch.randn(len(ts), B, T, 198, generator=g)
+    d = x0.clone()
+    eng.ddim_loop_(d, xc, ts, eta=0.5, noise=nz.cuda())
+    with torch.no_grad():
+        want = O.ddim_loop(sd, O.make_schedule(1000), x0.cpu(), xc_cpu, ts, eta=0.5, noise=nz)
+    assert (d.cpu() - want).abs().max().item() < POSE_TOL
+    with pytest.raises(_lib.EgoEgoHipError, match="eta"):
+        eng.ddim_loop_(d, xc, ts, eta=1.5)
 
 
 def test_default_torch_rng_path_draws_like_the_reference():

@@ -279,9 +279,11 @@ def test_mpjpe_matches_the_reference_definition():
 
 @pytest.mark.gpu
 def test_stage2_entry_point_on_the_demo_trajectory(hg, tmp_path):
-    """tools/run_stage2_demo.py with the reference's --diffusion_* flags on the 140-frame demo head trajectory, the real
-    statistics and synthetic weights: two windows (120 + 30 frames), finite outputs of the reference's shapes, an MPJPE
-    against the demo's own FK joints, and the same numbers as calling the harness directly."""
+    """tools/run_stage2_demo.py with the reference's --diffusion_* flags on the 140-frame demo head trajectory and the real
+    statistics: two windows (120 + 30 frames), outputs of the reference's shapes, an MPJPE against the demo's own FK
+    joints — and THE SAME NUMBERS as (a) calling the harness directly (bit for bit, Philox run on synthetic weights) and
+    (b) the numpy/scipy oracle on injected draws (a checkpoint in the reference's file layout with a trained-like output
+    head; 1e-4 m / 1e-3 rad like the direct harness test)."""
     import importlib.util
     import pickle
     spec = importlib.util.spec_from_file_location("run_stage2_demo", os.path.join(ROOT, "tools", "run_stage2_demo.py"))
@@ -295,13 +297,50 @@ def test_stage2_entry_point_on_the_demo_trajectory(hg, tmp_path):
     aa_gt = np.concatenate([hg["demo_root_orient"][:, None], hg["demo_body_pose"].reshape(-1, 21, 3)], 1)
     _, gj = dso.fk(hg["demo_trans"], aa_gt)
     np.save(tmp_path / "gt.npy", gj)
-    argv = ["--head_pose", str(tmp_path / "head.npy"), "--stats", str(tmp_path / "stats.p"), "--rest_offsets", str(tmp_path / "rest.npy"),
-            "--gt_jpos", str(tmp_path / "gt.npy"), "--diffusion_window", "120", "--diffusion_batch_size", "2", "--timesteps", "5",
-            "--sampling_rng", "philox", "--seed", "3", "--out", str(tmp_path / "out.npz"), "--use_min_max", "--canonicalize_init_head"]
-    rep = mod.main(argv)
+    common = ["--head_pose", str(tmp_path / "head.npy"), "--stats", str(tmp_path / "stats.p"), "--rest_offsets", str(tmp_path / "rest.npy"),
+              "--gt_jpos", str(tmp_path / "gt.npy"), "--diffusion_window", "120", "--diffusion_batch_size", "2", "--use_min_max",
+              "--canonicalize_init_head"]
+    # ---- (a) Philox run on the synthetic weights == the harness called directly
+    rep = mod.main(common + ["--timesteps", "5", "--sampling_rng", "philox", "--seed", "3", "--out", str(tmp_path / "out.npz")])
     assert rep["frames"] == 140 and rep["samples"] == 2 and rep["windows"] == 2 and len(rep["mpjpe_mm"]) == 2
     out = np.load(tmp_path / "out.npz")
     assert out["local_aa"].shape == (2, 140, 22, 3) and out["root_trans"].shape == (2, 140, 3) and out["global_jpos"].shape == (2, 140, 22, 3)
     assert all(np.isfinite(out[k]).all() for k in out.files) and all(np.isfinite(v) and v > 0 for v in rep["mpjpe_mm"])
     # the two samples share the head trajectory and (Philox keyed by window index) differ in their noise
     assert not np.array_equal(out["local_aa"][0], out["local_aa"][1])
+    cfg = ModelConfig(max_timesteps=121)
+    m = harness.build_stage2_model(window=120)
+    m.load_state_dict(make_weights(cfg, 0), strict=False)
+    m = m.cuda()
+    m.num_timesteps, m.sampling_rng, m.philox_seed = 5, "philox", 3
+    head_pose = torch.from_numpy(hg["demo_head_qpos"]).float()[None].repeat_interleave(2, 0).cuda()
+    torch.manual_seed(3)
+    aa, root = harness.full_body_gen_cond_head_pose_sliding_window(m, ds, head_pose)
+    assert np.array_equal(out["local_aa"], aa.cpu().numpy()) and np.array_equal(out["root_trans"], root.cpu().numpy())
+    gq_d, gj_d = ds.fk_smpl(root.reshape(-1, 3), aa.reshape(-1, 22, 3))
+    assert np.array_equal(out["global_jpos"], gj_d.reshape(2, 140, 22, 3).cpu().numpy())
+    assert abs(rep["mpjpe_mm"][0] - mod.mpjpe_mm(out["global_jpos"][0], gj)) < 1e-9
+    # ---- (b) checkpoint file in the reference's layout + injected draws == the oracle's sliding window
+    S, T = 6, 140
+    sd = _trained_like_weights(hg, dso, cfg)
+    ref_model = harness.build_stage2_model(window=120)
+    ref_model.load_state_dict(sd, strict=False)
+    full = ref_model.state_dict()
+    torch.save({"step": 7, "model": {k: torch.zeros_like(v) for k, v in full.items()},  # the EMA weights are the ones used
+                "ema": {**{"ema_model." + k: v for k, v in full.items()}, "initted": torch.tensor(True), "step": torch.tensor(7)},
+                "scaler": {}}, tmp_path / "model-7.pt")
+    g = torch.Generator().manual_seed(15)
+    wins = [(0, 120), (110, 140)]
+    noise = {"x_all": torch.randn(2, T, 198, generator=g), "cond": [torch.randn(2, b - a, 198, generator=g) for a, b in wins],
+             "steps": [torch.randn(S, 2, b - a, 198, generator=g) for a, b in wins]}
+    torch.save(noise, tmp_path / "noise.pt")
+    rep = mod.main(common + ["--timesteps", str(S), "--weight", str(tmp_path / "model-7.pt"), "--noise", str(tmp_path / "noise.pt"),
+                             "--out", str(tmp_path / "out2.npz")])
+    assert rep["checkpoint"]["step"] == 7 and not rep["checkpoint"]["unexpected"]
+    out2 = np.load(tmp_path / "out2.npz")
+    hp = head_pose.cpu()
+    aa2, root2 = HO.sliding_window(sd, O.make_schedule(1000), dso, 120, S, hp[..., :3].double().numpy(), hp[..., 3:].double().numpy(),
+                                   O.head_condition_mask((2, T, 198)), noise)
+    assert np.abs(out2["root_trans"] - root2).max() < 1e-4, np.abs(out2["root_trans"] - root2).max()
+    ang = _angle(out2["local_aa"], aa2)
+    assert ang.max() < 1e-3, (ang.max(), np.median(ang))

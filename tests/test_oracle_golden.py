@@ -85,3 +85,46 @@ def test_head_condition_mask():
     m = O.head_condition_mask((2, 5, 198))
     assert m.sum().item() == 2 * 5 * (198 - 9)
     assert m[..., 45:48].sum() == 0 and m[..., 156:162].sum() == 0
+
+
+def test_p_sample_loop_with_padding_mask_matches_reference(golden):
+    """M:259, 268: p_sample_loop hands its padding_mask to every step.  Fixture: the reference's own 10-step chain."""
+    from egoego_release_amd import make_head_windows
+    cfg = ModelConfig()
+    sd = make_weights(cfg, 0)
+    xs, cm = make_head_windows(2, 120, seed=13)
+    pm = torch.ones(2, 1, 121).bool()
+    pm[0, 0, 100:] = False
+    pm[1, 0, 61:] = False
+    with torch.no_grad():
+        y = O.p_sample_loop(sd, O.make_schedule(1000), xs, cm, torch.Generator().manual_seed(321), num_timesteps=10, padding_mask=pm)
+    _close(y.numpy(), golden["sample_padmask_b2_s10"])
+
+
+def test_ddim_eta1_full_list_is_the_ancestral_step():
+    """the DDIM restatement is tied to the reference's chain by eta = 1 on consecutive timesteps down
+    to 0, where its update equals p_sample (pinned above) up to rounding: same mean (c1 x0 + c2 x_t), sig^2 =
+    posterior variance, no noise on the last step.  (The full 999..0 list runs on the GPU: test_gpu_parity.py.)"""
+    cfg = ModelConfig()
+    sd = make_weights(cfg, 0)
+    sched = O.make_schedule(1000)
+    g = torch.Generator().manual_seed(4)
+    x, xc = torch.randn(1, 120, 198, generator=g), torch.randn(1, 120, 198, generator=g)
+    ts = list(range(30, -1, -1))
+    nz = torch.randn(len(ts), 1, 120, 198, generator=g)
+    with torch.no_grad():
+        a = O.ddim_loop(sd, sched, x.clone(), xc, ts, eta=1.0, noise=nz)
+        b = x.clone()
+        for i, t in enumerate(ts):
+            b = O.p_sample(sd, sched, b, torch.full((1,), t), xc, nz[i])
+    assert (a - b).abs().max().item() < 2e-5, (a - b).abs().max().item()
+    # the coefficients themselves over the whole schedule: sig_t^2 = posterior variance, mean coefficients agree (the
+    # registered buffers are fp32 roundings of float64 values; recomputing from the fp32 alphas_cumprod costs ~1e-3
+    # relative where 1 - abar is small)
+    abar = sched["alphas_cumprod"].double()
+    ap = torch.cat((torch.ones(1, dtype=torch.float64), abar[:-1]))
+    sig2 = (1 - ap) / (1 - abar) * (1 - abar / ap)
+    assert torch.allclose(sig2[1:].float(), sched["posterior_variance"][1:], rtol=2e-3, atol=1e-12)
+    c_eps = (1 - ap - sig2).clamp(min=0).sqrt() / (1 - abar).sqrt()       # x_t coefficient of the DDIM mean
+    assert torch.allclose(c_eps.float(), sched["posterior_mean_coef2"], rtol=2e-3, atol=1e-6)
+    assert torch.allclose((ap.sqrt() - c_eps * abar.sqrt()).float(), sched["posterior_mean_coef1"], rtol=2e-3, atol=1e-6)

@@ -87,6 +87,8 @@ def parse_opt(argv=None):
     p.add_argument("--timesteps", type=int, default=1000, help="diffusion steps (lower = truncated chain, for smoke runs)")
     p.add_argument("--sampling_rng", default="torch", choices=("torch", "philox"))
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--noise", default="", help="torch-saved dict {'x_all','cond','steps'} of injected draws (harness.py "
+                                               "p_sample_loop_sliding_window_w_canonical): reproducibility / parity runs")
     p.add_argument("--out", default="stage2_out.npz")
     return p.parse_args(argv)
 
@@ -118,7 +120,8 @@ def main(argv=None):
     torch.manual_seed(opt.seed)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    aa, root = harness.full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose)
+    noise = torch.load(opt.noise, map_location="cpu") if opt.noise else None
+    aa, root = harness.full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=noise)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     # global joints through FK, as run_egoego.py:152-158 does with ds.fk_smpl
