@@ -272,17 +272,22 @@ def main():
                     "utilisation is 3x this fraction"}
         Lp = 32 if L <= 32 else 64 if L <= 64 else 128 if L <= 128 else 224       # padded rows per window (make_geometry)
         rows_p = (Bl * Lp + 255) // 256 * 256                                     # padded token rows of this rank's shard
-        tail_name = "layer_tail_kernel" if rows_p // 128 > 128 else "tail_kernel"  # the library's dispatch (run_chunk_np: tb_b <= 128 -> tail_kernel)
+        big_tail = rows_p // 128 > 128   # the library's dispatch (run_chunk_np: tb_b <= 128 -> tail_kernel)
+        tail_name = ("layer_tail_i8_kernel" if args.precision == 8 else "layer_tail_kernel") if big_tail else "tail_kernel"
+        ffn_txt = "FFN on int8 slices" if args.precision == 8 else "FFN split-bf16"
+        tail_txt = ((" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, two workgroups per CU, LDS-ring operands; "
+                     f"fc split-bf16, {ffn_txt}" + (" in two passes into one int32 accumulator)" if args.precision == 8 else ")"))
+                    if big_tail else
+                    (" (the same three GEMMs per 32/64 tokens for small batches: weights streamed into registers, activations by LDS-DMA "
+                     f"chunks; fc split-bf16, {ffn_txt})"))
         tail_roof = {
-            "bound": "mfma", "kernel": tail_name + (" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, two workgroups per CU, "
-                                                    "LDS-ring operands, split-bf16)" if tail_name == "layer_tail_kernel" else
-                                                    " (the same three GEMMs per 32/64 tokens for small batches: weights streamed into registers, "
-                                                    "activations by LDS-DMA chunks, split-bf16)"),
+            "bound": "mfma", "kernel": tail_name + tail_txt,
             "achieved": tail_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (tail_ach / PEAK_BF16_TFLOPS) if tail_ach else None,
             "traffic": (traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
             "algorithmic_bytes": 4 * Bl * L * (1024 + 512 + 512) + 4.2e6,
             "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * ms_step) if t_n else None,
-            "note": "measured like the attention-layer kernel; split-bf16 issues 3 MFMAs per product (pipe utilisation 3x)"}
+            "note": "measured like the attention-layer kernel; 3 MFMAs are issued per product (split-bf16: K=16 per MFMA; int8 slices: K=32 per "
+                    "MFMA at the same issue time), so the fraction is normalised by the bf16 peak although half the FLOPs run on int8 MFMAs"}
         dominant, other = (attn_roof, tail_roof) if (k_us or 0) >= (t_us or 0) else (tail_roof, attn_roof)
         out_json = {
             "metric": f"diffusion-steps/sec (B={B}, T={T}, 22-joint)",
@@ -295,7 +300,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": {8: "i8x3 + bf16x3 (attention layer: 2 x int8 slices per operand, int32 accumulate; rest: split-bf16, fp32 accumulate)",
+            "dtype": {8: "i8x3 + bf16x3 (attention layer and FFN: 2 x int8 slices per operand, int32 accumulate; embed, fc, linear_out: split-bf16, fp32 accumulate)",
                       3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)", 1: "bf16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: B={B} windows x T={T} frames x 198 feats split over {world} GPU(s) "

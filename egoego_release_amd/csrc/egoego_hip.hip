@@ -48,6 +48,8 @@ struct LayerDev {
     __bf16 *w_qkv, *w_fc, *w_1, *w_2;  // fragment-tiled, 2 planes each
     int8_t* w_qkv8n;                   // i8x3 copy of w_qkv for attn_layer_i8_kernel: two slices, K in acc32 order
     float* s_qkv;                      // its row scales [3*HD]
+    int8_t *w_1_8, *w_2_8;             // i8x3 copies of the FFN weights: two slices of [512][512], K in acc32 order
+    float *s_1, *s_2;                  // their row scales [512]
     float *b_qkv, *b_fc, *ln1_g, *ln1_b, *b_1, *b_2, *ln2_g, *ln2_b;
 };
 
@@ -134,6 +136,8 @@ struct Workspace {
     size_t xall_plane, h_plane, qkv_plane, o_plane;
     int8_t* hA8;      // int8 slices of hA (i8x3 consumers), slice stride h_plane bytes
     float* hA_scale;  // [Mp]
+    int8_t *hB8, *F8;           // i8x3 FFN: LayerNorm-1 output and ReLU output as int8 slices (same layout as hA8)
+    float *hB_scale, *F_scale;  // [Mp] their row scales
     float *sq8, *sk8, *sv8;  // [B*H][Lp] row scales of the int8 Q / K / V images (attn_core_i8.h; the images alias Q, K, V)
     size_t total;
 };
@@ -164,6 +168,10 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
     w.O = (__bf16*)take(2 * w.o_plane * 2);
     w.hA8 = (int8_t*)take(2 * w.h_plane);
     w.hA_scale = (float*)take(sizeof(float) * g.Mp);
+    w.hB8 = (int8_t*)take(2 * w.h_plane);
+    w.hB_scale = (float*)take(sizeof(float) * g.Mp);
+    w.F8 = (int8_t*)take(2 * w.h_plane);
+    w.F_scale = (float*)take(sizeof(float) * g.Mp);
     w.sq8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
     w.sk8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
     w.sv8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
@@ -246,6 +254,57 @@ __global__ __launch_bounds__(C::NT, C::MINW) void layer_tail_kernel(GemmOperands
     __syncthreads();
     GemmBody<C, ELN>::run(g_2, e_2, 0, tblk, smem);
 }
+
+// The same with the two FFN contractions on int8 slices ("i8x3", the default precision).  A 256-register wave cannot
+// hold the I8Acc pair of its 128-feature x 64-token tile, so each contraction runs as TWO passes over K into ONE int32
+// accumulator (gemm.h I8One): high slices only (half the operand stream), shift by 8, then the two cross terms on top —
+// the exact integer the one-pass form of tail_kernel produces, hence the same bits downstream.  Against split-bf16 the
+// FFN main loops issue half the MFMAs and stream 3/4 of the operand bytes; LayerNorm-1 also emits its rows as int8
+// slices (the operand of FFN-1) and FFN-1's epilogue quantises the ReLU output per row (the operand of FFN-2), so the
+// hidden activations cross memory as 2 instead of 4 bytes per value.
+// stop (debug taps): 1 = return after LayerNorm-1, 2 = after FFN-1.
+template <class C, class C8a, class C8b, class ELN, class ERQ>
+__global__ __launch_bounds__(C::NT, C::MINW) void layer_tail_i8_kernel(GemmOperands g_fc, ELN e_fc, GemmOperands g_1, const float* sw1, ERQ e_1,
+                                                                         GemmOperands g_2, const float* sw2, ELN e_2, int stop) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tblk = (int)blockIdx.x + g_fc.tblk0;
+    GemmBody<C, ELN>::run(g_fc, e_fc, 0, tblk, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stop == 1) return;
+    const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
+    const int wf = wave % C::NWF, wt = wave / C::NWF;
+    const int f0 = wf * C::FT * 32, t0 = (tblk * C::AT + wt * C::TT) * 32;
+    auto i8_gemm = [&](const GemmOperands& g8, I8One (&q)[C::FT][C::TT]) {
+        GemmBody<C8a, ELN>::template mainloop<I8One, true>(g8, 0, tblk, smem, q);
+#pragma unroll
+        for (int i = 0; i < C::FT; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q[i][j].v[r] <<= 8;
+        GemmBody<C8b, ELN>::template mainloop<I8One, false>(g8, 0, tblk, smem, q);
+    };
+    {
+        I8One q[C::FT][C::TT];
+        i8_gemm(g_1, q);
+        e_1.template run<I8One, C::FT, C::TT>(q, sw1, e_fc.q8_scale, f0, t0, lane, wf, wt, smem);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stop == 2) return;
+    {
+        I8One q[C::FT][C::TT];
+        i8_gemm(g_2, q);
+        f32x16 acc[C::FT][C::TT];
+        i8_dequant_tile(q, acc, sw2, e_1.q8_scale, f0, t0, lane);
+        e_2.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
+    }
+}
+// the int8 FFN passes of the 512f x 64t, 4-wave tile: pass 1 stages the high slices of two k-blocks per ring stage, pass 2 both
+// slices of one — 36 KiB per stage either way, the ring of the split-bf16 phase
+using CfgT8a = GemmCfg<4, 2, 4, 1, 2, 1, false, 2, 2>;
+using CfgT8b = GemmCfg<4, 2, 4, 1, 1, 2, false, 2, 2>;
 
 // ------------------------------------------------------------------------------------ launch helpers
 struct ProfScope {
@@ -336,19 +395,23 @@ static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
 }
 
 // Fused small-batch tail (tail_fused.h): 64-token workgroups when they fill the CUs exactly once, 32-token ones below.
-static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
+template <bool FFN8>
+static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        HIP_TRY(allow_smem(tail_kernel<2>, tail_smem_bytes(2)));
-        HIP_TRY(allow_smem(tail_kernel<1>, tail_smem_bytes(1)));
+        HIP_TRY(allow_smem(tail_kernel<2, FFN8>, tail_smem_bytes(2)));
+        HIP_TRY(allow_smem(tail_kernel<1, FFN8>, tail_smem_bytes(1)));
         once = true;
     }
     if (rows / 64 >= 256)
-        tail_kernel<2><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
+        tail_kernel<2, FFN8><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
     else
-        tail_kernel<1><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+        tail_kernel<1, FFN8><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
+    return ta.ffn8 ? launch_tail_f<true>(ta, rows, s) : launch_tail_f<false>(ta, rows, s);
 }
 
 // The direct-operand embed / linear_out kernels run 32-token workgroups (TT = 1) at every size they are used for
@@ -460,6 +523,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // the fused kernel has one workgroup per (window, head): below ~one workgroup per CU the unfused pair
         // (12 projection blocks per window) spreads the same work over more CUs
         const bool i8 = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;
+        const bool ffn8 = i8;  // i8x3: the FFN contractions run on int8 slices too (every batch size: same integers, same bits)
         const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && (i8 || nw * H >= 192);
         const bool fused_attn = attn_geom && !dbg_qkv;
         // the layer's output also as int8 slices: the next layer's projections consume them
@@ -554,6 +618,13 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 ta.o = w.O; ta.o_plane = w.o_plane; ta.HD16 = HD / 16;
                 ta.wfc = L.w_fc; ta.wfc_plane = (size_t)N_MODEL * HD;
                 ta.ln1 = EpiResLN<2, 4, 0>{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f, nullptr, 0, nullptr};
+                if (ffn8) {  // FFN on int8 slices: LayerNorm-1 also emits int8 rows, FFN-1 writes int8 rows
+                    ta.ffn8 = 1;
+                    ta.ln1.q8 = w.hB8; ta.ln1.q8_plane = w.h_plane; ta.ln1.q8_scale = w.hB_scale;
+                    ta.w1_8 = L.w_1_8; ta.w2_8 = L.w_2_8; ta.w8_plane = (size_t)N_MODEL * N_MODEL;
+                    ta.s_w1 = L.s_1; ta.s_w2 = L.s_2;
+                    ta.relu8 = EpiReluQ8<4, 0>{L.b_1, w.F8, w.h_plane, w.F_scale};
+                }
                 ta.w1 = L.w_1; ta.w1_plane = (size_t)N_MODEL * N_MODEL;
                 ta.relu = EpiTiled<true, 2>{L.b_1, w.F, w.h_plane, N_MODEL / 16};
                 ta.w2 = L.w_2; ta.w2_plane = (size_t)N_MODEL * N_MODEL;
@@ -564,6 +635,30 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 if (last_dbg) return 0;
                 continue;
             }
+        }
+        if (ffn8) {
+            // --- fused layer tail with the FFN on int8 slices (every batch size above the small-batch kernel's; debug taps through `stop`)
+            ProfScope ps(c, EGOEGO_K_FC_LN, s);
+            const int nb = rows / 64, b0 = row0 / 64;
+            const size_t wp8 = (size_t)N_MODEL * N_MODEL / 2;  // slice stride in the main loop's 2-byte units
+            GemmOperands g1{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, nb, b0 EG_DBG(, g_ablate, g_trace)};
+            EpiResLN<NP, 4, 64> e1{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f, w.hB8, w.h_plane, w.hB_scale};
+            GemmOperands g2{(const __bf16*)L.w_1_8, wp8, (const __bf16*)w.hB8, w.h_plane / 2, N_MODEL / 32, 1, nb, b0 EG_DBG(, 0, nullptr)};
+            EpiReluQ8<4, 64> e2{L.b_1, w.F8, w.h_plane, w.F_scale};
+            GemmOperands g3{(const __bf16*)L.w_2_8, wp8, (const __bf16*)w.F8, w.h_plane / 2, N_MODEL / 32, 1, nb, b0 EG_DBG(, 0, nullptr)};
+            EpiResLN<NP, 4, 64> e3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+            auto kern = layer_tail_i8_kernel<CfgBs<NP>, CfgT8a, CfgT8b, EpiResLN<NP, 4, 64>, EpiReluQ8<4, 64>>;
+            static_assert(CfgT8a::SMEM_BYTES <= CfgBs<2>::SMEM_BYTES && CfgT8b::SMEM_BYTES <= CfgBs<2>::SMEM_BYTES, "the int8 passes reuse the split-bf16 ring");
+            static bool once = false;
+            if (!once) {
+                HIP_TRY(allow_smem(kern, CfgBs<NP>::SMEM_BYTES));
+                once = true;
+            }
+            const int stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
+            kern<<<dim3(nb), dim3(CfgBs<NP>::NT), CfgBs<NP>::SMEM_BYTES, s>>>(g1, e1, g2, L.s_1, e2, g3, L.s_2, e3, stop);
+            HIP_TRY(hipGetLastError());
+            if (last_dbg) return 0;
+            continue;
         }
         if (!small_ln && !last_dbg) {
             // --- fused layer tail: fc+LN -> FFN-1 -> FFN-2+LN per 64-token block, two workgroups per CU (TM:92-93, 111-114, 135, 139)
@@ -854,6 +949,13 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
         if ((r = pack_weight(lw.w_1, N_MODEL, N_MODEL, N_MODEL, 0, L.w_1, (size_t)N_MODEL * N_MODEL, N_MODEL / 16, 0, 0, s))) return r;
         if ((r = dev_alloc(c, (void**)&L.w_2, (size_t)2 * N_MODEL * N_MODEL * 2, false, s))) return r;
         if ((r = pack_weight(lw.w_2, N_MODEL, N_MODEL, N_MODEL, 0, L.w_2, (size_t)N_MODEL * N_MODEL, N_MODEL / 16, 0, 0, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.w_1_8, (size_t)2 * N_MODEL * N_MODEL, false, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.w_2_8, (size_t)2 * N_MODEL * N_MODEL, false, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.s_1, sizeof(float) * N_MODEL, false, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.s_2, sizeof(float) * N_MODEL, false, s))) return r;
+        k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_1, N_MODEL, N_MODEL, L.w_1_8, (size_t)N_MODEL * N_MODEL, L.s_1, 0);
+        k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_2, N_MODEL, N_MODEL, L.w_2_8, (size_t)N_MODEL * N_MODEL, L.s_2, 0);
+        HIP_TRY(hipGetLastError());
         if ((r = copy_vec(c, &L.b_fc, lw.b_fc, N_MODEL, N_MODEL, s))) return r;
         if ((r = copy_vec(c, &L.ln1_g, lw.ln1_g, N_MODEL, N_MODEL, s))) return r;
         if ((r = copy_vec(c, &L.ln1_b, lw.ln1_b, N_MODEL, N_MODEL, s))) return r;
@@ -1250,7 +1352,10 @@ int egoego_debug_stage(egoego_ctx* c, const float* d_x, const float* d_xc, const
             k_unpack_tiled<<<2048, 256, 0, s>>>(w.hB, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_FFN_HIDDEN:
-            k_unpack_tiled<<<2048, 256, 0, s>>>(w.F, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
+            if (c->cfg.precision == EGOEGO_PREC_I8X3)  // the hidden activations exist as int8 rows only
+                k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.F8, w.h_plane, w.F_scale, N_MODEL, g.Lp, L, B, d_out);
+            else
+                k_unpack_tiled<<<2048, 256, 0, s>>>(w.F, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_ATTN_OUT:
             k_unpack_tiled<<<2048, 256, 0, s>>>(w.O, w.o_plane, c->HD, g.Lp, L, B, d_out, lo);

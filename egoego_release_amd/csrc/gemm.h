@@ -117,11 +117,33 @@ EG_D void mma_part(int part, I8Acc& c, bf16x8 wh, bf16x8 wl, bf16x8 ah, bf16x8 a
     d = ACT_ROWS ? __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, d, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a, d, 0, 0, 0);
 }
 
+// int8 slices into ONE int32 accumulator, in two passes over K ("i8x3" where the register file has no room for the
+// I8Acc pair): pass 1 (a configuration with NP == 1: only the high slices are staged) accumulates s1*s1; the caller
+// shifts the sums left by 8; pass 2 (NP == 2, both slices staged) adds s2*s1 + s1*s2 on top.  Integer arithmetic is
+// exact, so the result equals i8_combine(h, m) of the one-pass form bit for bit (same bound: K <= 512).
+struct I8One {
+    i32x16 v;
+};
+EG_D void acc_zero(I8One& c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c.v[r] = 0;
+}
+template <int NP, bool ACT_ROWS>
+EG_D void mma_part(int part, I8One& c, bf16x8 wh, bf16x8 wl, bf16x8 ah, bf16x8 al) {
+    const i32x4 w = __builtin_bit_cast(i32x4, (NP == 2 && part == 0) ? wl : wh);
+    const i32x4 a = __builtin_bit_cast(i32x4, (NP == 2 && part == 1) ? al : ah);
+    c.v = ACT_ROWS ? __builtin_amdgcn_mfma_i32_32x32x32_i8(a, w, c.v, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a, c.v, 0, 0, 0);
+}
+// MFMAs per (feature tile, token tile, k-step)
+template <class AccT, int NP> struct AccParts { static constexpr int N = NP == 2 ? 3 : 1; };
+template <int NP> struct AccParts<I8One, NP> { static constexpr int N = NP == 2 ? 2 : 1; };
+
 template <class C, class Epi>
 struct GemmBody {
     // main loop only: on return acc[ft][tt] holds the pre-epilogue sums of this wave's tile.
     // AccT = f32x16 (bf16 operands) or I8Acc (int8 slices: g.K16 then counts 32-wide k blocks).
-    template <class AccT>
+    // ZERO = false: accumulate on top of what acc holds (second pass of the I8One form)
+    template <class AccT, bool ZERO = true>
     static __device__ void mainloop(const GemmOperands& g, int fblk, int tblk, char* smem, AccT (&acc)[C::FT][C::TT]) {
         constexpr int FT = C::FT, TT = C::TT, KS = C::KS, NP = C::NP, WT = C::WT, AT = C::AT, NW = C::NW;
         constexpr int NCH = C::NCH;
@@ -153,10 +175,12 @@ struct GemmBody {
             gp[j] = base + lane;
         }
 
+        if (ZERO) {
 #pragma unroll
-        for (int i = 0; i < FT; ++i)
+            for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
+                for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
+        }
 
         const int ns = g.K16 / KS;
         // ---- software pipeline -------------------------------------------------------------------
@@ -203,7 +227,7 @@ struct GemmBody {
         // MFMAs of one half (FH x TT accumulator triples, part-major).  DMA instruction q of (stage, slot) is issued
         // after MFMA q - q0, so the DMA issue cost is paid in the shadow of the matrix pipe.
         auto mfmas = [&](const ActFr& a, const WFr& w, int half, bool dma, int stage, int slot, int q0, auto&& after_first, auto&& reads) {
-            constexpr int NPART = NP == 2 ? 3 : 1;
+            constexpr int NPART = AccParts<AccT, NP>::N;
             constexpr int NMMA = NPART * FH * TT;
             constexpr int PER = (NCH + 2 * NMMA - 1) / (2 * NMMA);
 #pragma unroll
@@ -225,7 +249,7 @@ struct GemmBody {
                             }
                     }
         };
-        constexpr int NMMA_HALF = (NP == 2 ? 3 : 1) * FH * TT;
+        constexpr int NMMA_HALF = AccParts<AccT, NP>::N * FH * TT;
         constexpr int DMA_PER_HALF = ((NCH + 2 * NMMA_HALF - 1) / (2 * NMMA_HALF)) * NMMA_HALF;
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -403,6 +427,37 @@ EG_D void i8_dequant(const I8Acc& q, f32x16& o, const float* sw8, float sa) {
         for (int c = 0; c < 4; ++c) o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sa256 * ws[c]);
     }
 }
+// the same from the one-accumulator form (its integer IS i8_combine(h, m)): same float operations, same bits
+EG_D void i8_dequant(const I8One& q, f32x16& o, const float* sw8, float sa) {
+    const float sa256 = sa * 256.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w4 = *(const float4*)(sw8 + 8 * g);
+        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[4 * g + c] = (float)q.v[4 * g + c] * (sa256 * ws[c]);
+    }
+}
+// A whole wave tile: acc[i][j] = dequantised sums of feature tile i (weight row scales sw[f0 + 32 i ..]) and token tile j
+// (activation row scales sa[t0 + 32 j + col]); what an fp32 epilogue (EpiResLN, EpiReluQ8) then takes.
+template <class QT, int FT, int TT>
+EG_D void i8_dequant_tile(const QT (&q)[FT][TT], f32x16 (&acc)[FT][TT], const float* sw, const float* sa, int f0, int t0, int lane) {
+    const int hf = lane >> 5, col = lane & 31;
+    float s[TT];
+#pragma unroll
+    for (int j = 0; j < TT; ++j) s[j] = sa[t0 + j * 32 + col];
+    // one feature tile at a time (its 16 weight scales are loaded once for all token tiles); the compiler-level fences keep
+    // hipcc from hoisting every tile's scale loads to the top, which costs more registers than the wave has
+#pragma unroll
+    for (int i = 0; i < FT; ++i) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TT; ++j) i8_dequant(q[i][j], acc[i][j], sw + f0 + i * 32 + 4 * hf, s[j]);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // ... and the epilogue's loads from moving up beside the still-live integer sums
+}
 // un-swapped accumulator (lane owns a feature, registers walk tokens)
 EG_D void i8_dequant_rows(const I8Acc& q, f32x16& o, float sw, const float* sa8) {
     const float sw256 = sw * 256.0f;
@@ -453,6 +508,87 @@ struct EpiTiled {
                     *(u32x4*)(out + idx) = hi;
                     if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
                 }
+            }
+    }
+};
+
+// bias + ReLU -> the rows as int8 slices with one scale per row (i8x3 FFN: the hidden activations of TM:111 are the
+// int8 operand of the second conv).  The block must span all 512 hidden features (NWF * FT * 32 == 512): the row maximum
+// is taken in-lane over the wave's tiles, across the two halves by a shuffle and across the NWF waves through LDS.
+template <int NWF, int BT>
+struct EpiReluQ8 {
+    const float* bias;   // [512]
+    int8_t* q8;          // fragment-tiled int8 rows [Mp][512], K in acc32 order; second slice at + q8_plane
+    size_t q8_plane;
+    float* q8_scale;     // [Mp]
+    // q: the integer sums of an int8-slice contraction (I8Acc or I8One); sw / sa: weight-row and activation-row scales.
+    // Two sweeps over the INTEGER sums, one tile at a time (a tile's 16 scales and 16 biases in registers; the fences keep
+    // hipcc from hoisting every tile's loads to the top): the first only takes the row maximum of relu(dequant + bias),
+    // the second recomputes those values and quantises them straight into the stores.  No fp32 copy of the wave tile
+    // ever exists, which is what lets a 256-register wave (128 of them integer sums) run this without spilling.
+    template <class QT, int FT, int TT>
+    __device__ void run(const QT (&q)[FT][TT], const float* sw, const float* sa, int f0, int t0, int lane, int wf, int wt, char* smem) const {
+        static_assert(NWF * FT * 32 == 512, "the row maximum needs the whole 512-wide row in the block");
+        const int hf = lane >> 5, col = lane & 31;
+        float* red = (float*)smem;  // [TT][NWF][BT]
+        float amax[TT], s[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            amax[j] = 0.f;
+            s[j] = sa[t0 + j * 32 + col];
+        }
+        auto tile = [&](int i, int j, f32x16& v) {  // relu(dequant + bias) of one tile
+            i8_dequant(q[i][j], v, sw + f0 + i * 32 + 4 * hf, s[j]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *(const float4*)(bias + f0 + i * 32 + 8 * g + 4 * hf);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[4 * g + c] = fmaxf(v[4 * g + c] + bb[c], 0.f);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 v;
+                tile(i, j, v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) amax[j] = fmaxf(amax[j], v[r]);
+            }
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            amax[j] = fmaxf(amax[j], __shfl_xor(amax[j], 32));
+            if (hf == 0) red[(j * NWF + wf) * BT + (wt * TT + j) * 32 + col] = amax[j];
+        }
+        __syncthreads();
+        float inv[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            float rmax = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red[(j * NWF + w) * BT + (wt * TT + j) * 32 + col]);
+            inv[j] = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+            if (wf == 0 && hf == 0) q8_scale[t0 + j * 32 + col] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 v;
+                tile(i, j, v);
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = v[r];
+                u32x4 s1, s2;
+                quant16(t, inv[j], s1, s2);
+                const size_t idx = acc_slot_i8(t0 + j * 32 + col, f0 + i * 32, hf, 16);
+                *(u32x4*)(q8 + idx) = s1;
+                *(u32x4*)(q8 + q8_plane + idx) = s2;
             }
     }
 };

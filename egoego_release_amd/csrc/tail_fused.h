@@ -19,6 +19,8 @@
 // lo*hi, hi*lo, hi*hi) and the very same epilogue code (gemm.h EpiResLN / EpiTiled), so a window's numbers do not depend
 // on the batch it is sampled in (tests: batch-size and shard invariance).
 #pragma once
+#include <type_traits>
+
 #include "gemm.h"
 
 // perf-debug ablations of the k-loop (compile-time, results become wrong): 1 = no weight loads, 2 = no LDS fragment
@@ -42,6 +44,15 @@ struct TailArgs {
     const __bf16* w2;
     size_t w2_plane;
     EpiResLN<2, 4, 0> ln2;   // bias, residual hb, gamma/beta, row mask, output (+ optional int8 copy)
+    // i8x3 FFN (ffn8 != 0): w_1 / w_2 as int8 slices with one scale per output row; LayerNorm-1 also emits int8 rows (ln1.q8),
+    // FFN-1 writes the ReLU output as int8 rows (relu8) and FFN-2 reads them
+    int ffn8;
+    const int8_t* w1_8;      // [512][512] two slices, w8_plane BYTES apart
+    const int8_t* w2_8;
+    size_t w8_plane;
+    const float* s_w1;       // [512] weight row scales
+    const float* s_w2;
+    EpiReluQ8<4, 0> relu8;   // bias, int8 output rows + scales
     int stop;                // debug taps: 1 = return after LayerNorm-1, 2 = after FFN-1, 0 = run everything
     EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][32] phase timestamps or nullptr
 };
@@ -68,8 +79,11 @@ EG_D i32x4 tail_load(tail_rsrc r, int voff, unsigned soff) {
 // k-step 0 through dma(piece) (loads return in order: issued first, they have the whole chunk to land).
 // Activation fragments: the hi plane is double-buffered (read a k-step ahead), the lo plane is re-read right after the
 // one MFMA group that uses it; each fragment is consumed >= FT*TT MFMAs after its read was issued.
-template <int FT, int TT, int RING, bool LAST, int DP, int NKS = 8>
+// I8 = true: the operands are int8 slices (k-blocks of 32; "hi" plane = slice 1, "lo" plane = slice 2) and the sums go to
+// an I8Acc pair — s2*s1 and s1*s2 into .m, s1*s1 into .h, the groups in the order of the split-bf16 parts.
+template <int FT, int TT, int RING, bool LAST, int DP, int NKS = 8, bool I8 = false>
 struct TailChunk {
+    using AccT = typename std::conditional<I8, I8Acc, f32x16>::type;
     static constexpr int PD = RING - 1, NW = FT * 2;  // NKS < 8: the short last chunk of a contraction whose k-blocks are no multiple of 8
     static_assert(NKS == 8 || (LAST && DP == 0), "only the last chunk may be short");
     static_assert(RING == 2 || RING == 4 || RING == 8, "ring slots must divide the 8 k-steps of a chunk");
@@ -92,13 +106,21 @@ struct TailChunk {
         }
         return n < 63 ? n : 63;
     }
-    static EG_D f32x16 mma(i32x4 w, i32x4 a, f32x16 c) {
-        if (TAIL_ABLATE & 8) return c;
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    // group 0: lo * hi, group 1: hi * lo, group 2: hi * hi
+    template <int G>
+    static EG_D void mma(i32x4 w, i32x4 a, f32x16& c) {
+        if (TAIL_ABLATE & 8) return;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    }
+    template <int G>
+    static EG_D void mma(i32x4 w, i32x4 a, I8Acc& c) {
+        if (TAIL_ABLATE & 8) return;
+        i32x16& d = G == 2 ? c.h : c.m;
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a, d, 0, 0, 0);
     }
 
     template <int KS, class Dma>
-    static EG_D void step(f32x16 (&acc)[FT][TT], i32x4 (&wq)[RING][NW], i32x4 (&ah)[2][TT], i32x4 (&al)[TT], tail_rsrc wr,
+    static EG_D void step(AccT (&acc)[FT][TT], i32x4 (&wq)[RING][NW], i32x4 (&ah)[2][TT], i32x4 (&al)[TT], tail_rsrc wr,
                           const unsigned (&wcur)[NW], const unsigned (&wnext)[NW], const char* act, int act_plane, int lane, Dma& dma) {
         constexpr int cur = KS & 1;
         // the weights and the hi-plane activations of this k-step have landed (counted: younger loads stay in flight)
@@ -128,14 +150,14 @@ struct TailChunk {
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i + 1], ah[cur][j], acc[i][j]);
+            for (int j = 0; j < TT; ++j) mma<0>(w[2 * i + 1], ah[cur][j], acc[i][j]);
         asm volatile("" ::: "memory");
         wait_counts<63, (KS < NKS - 1 ? TT : 0)>();  // the lo-plane activations of this k-step
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i], al[j], acc[i][j]);
+            for (int j = 0; j < TT; ++j) mma<1>(w[2 * i], al[j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         if (KS < NKS - 1) {
 #pragma unroll
@@ -146,12 +168,12 @@ struct TailChunk {
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int j = 0; j < TT; ++j) acc[i][j] = mma(w[2 * i], ah[cur][j], acc[i][j]);
+            for (int j = 0; j < TT; ++j) mma<2>(w[2 * i], ah[cur][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     }
 
     template <class Dma>
-    static EG_D void run(f32x16 (&acc)[FT][TT], i32x4 (&wq)[RING][NW], tail_rsrc wr, const unsigned (&wcur)[NW],
+    static EG_D void run(AccT (&acc)[FT][TT], i32x4 (&wq)[RING][NW], tail_rsrc wr, const unsigned (&wcur)[NW],
                          const unsigned (&wnext)[NW], const char* act, int act_plane, int lane, Dma dma) {
         i32x4 ah[2][TT], al[TT];
 #pragma unroll
@@ -178,15 +200,18 @@ struct TailChunk {
 // in / w: split-bf16 fragment-tiled tensors with K16 = K / 16 k-blocks per row tile: a multiple of 8, or (REM2) a multiple of
 // 8 plus 2 — the embed operand's 26 k-blocks.  `act` is the
 // chunk double buffer in LDS (TT * 32 KiB).  Feature tile i of wave `wave` is tile wave * FT + i of W.
-template <int FT, int TT, int RING, bool REM2 = false>
+// I8: int8-slice operands ([R/32][K/32][2][32][16] byte planes, the two slices `*_plane` bf16-element units = bytes / 2
+// apart; K16 then counts 32-wide k-blocks) accumulated into I8Acc pairs.
+template <int FT, int TT, int RING, bool REM2 = false, bool I8 = false>
 struct DirectGemm {
+    using AccT = typename std::conditional<I8, I8Acc, f32x16>::type;
     static constexpr int NW = 2 * FT, PD = RING - 1;
     static constexpr int CH_PLANE = TT * 8 * 1024, CH_BYTES = 2 * CH_PLANE;  // chunk buffer: [plane][t-tile][8 k-blocks][1 KiB]
     static constexpr int DMA_PIECES = 4 * TT;                                // 1-KiB pieces of a chunk per wave
     static constexpr int SMEM_BYTES = 2 * CH_BYTES;
 
     template <class Mark>
-    static EG_D void run(f32x16 (&acc)[FT][TT], const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, char* act,
+    static EG_D void run(AccT (&acc)[FT][TT], const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, char* act,
                          int tt0, int wave, int lane, Mark mark) {
         i32x4 wq[RING][NW];
         const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4), ir = tail_make_rsrc(in, in_plane * 4);
@@ -225,14 +250,14 @@ struct DirectGemm {
         for (int q = 0; q + 1 < NQ; ++q) {
             w_offsets(8 * q, wcur);
             w_offsets(8 * q + 8, wnext);
-            TailChunk<FT, TT, RING, false, DMA_PIECES>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
+            TailChunk<FT, TT, RING, false, DMA_PIECES, 8, I8>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
                                                              [&](int piece) { dma_piece(q + 1, piece); });
             // the next chunk has landed (counted wait inside run) and everyone is done with this one
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
         w_offsets(8 * (NQ - 1), wcur);
-        TailChunk<FT, TT, RING, true, 0, (REM2 ? 2 : 8)>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
+        TailChunk<FT, TT, RING, true, 0, (REM2 ? 2 : 8), I8>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
         __syncthreads();  // every wave is done with the chunk buffers before the next GEMM's first DMA
     }
 };
@@ -240,7 +265,9 @@ struct DirectGemm {
 // (Measured and NOT kept for B = 256: the same kernel with 2 ring slots, 256 registers and two co-resident 64-token workgroups per
 // CU — 278 us per launch against the 222 us of layer_tail_kernel, and no better with the second half of the grid started 20-80 us
 // late: a LayerNorm epilogue that takes 13 us alone takes 60 us next to a wave that saturates the matrix pipe of the same SIMD.)
-template <int TT>
+// FFN8: the two FFN contractions on int8 slices (TailArgs::ffn8 ...; the i8x3 precision) — a separate instantiation, so
+// that the split-bf16 kernel's register allocation is untouched.
+template <int TT, bool FFN8>
 __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     constexpr int TOK = 32 * TT, FT = 4;
     using G = DirectGemm<FT, TT, 4>;
@@ -277,6 +304,34 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     if (a.stop == 1) return;
 
     // =============================================================== 2. FFN w_1 + ReLU (TM:111)
+    if constexpr (FFN8) {
+        // int8 slices, one pass into I8Acc pairs (a lone wave per SIMD has the registers): the integer sums — and so every
+        // bit downstream — equal the two-pass one-accumulator form of the large-batch kernel (layer_tail_i8_kernel)
+        using G8 = DirectGemm<FT, TT, (TT == 2 ? 2 : 4), false, true>;  // TT = 2: 256 accumulator registers, so a 2-slot weight ring
+        const EpiReluQ8<4, TOK> e8{a.relu8.bias, a.relu8.q8, a.relu8.q8_plane, a.relu8.q8_scale};
+        {
+            I8Acc q[FT][TT];
+            G8::run(q, (const __bf16*)a.ln1.q8, a.ln1.q8_plane / 2, 16, (const __bf16*)a.w1_8, a.w8_plane / 2, act, tt0, wave, lane, [&] { mark(8); });
+            mark(3);
+            e8.template run<I8Acc, FT, TT>(q, a.s_w1, a.ln1.q8_scale, wave * FT * 32, tok0, lane, wave, 0, red);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mark(4);
+        if (a.stop == 2) return;
+        // =========================================================== 3. FFN w_2 + residual + LayerNorm (TM:111-114, 139)
+        {
+            I8Acc q[FT][TT];
+            G8::run(q, (const __bf16*)a.relu8.q8, a.relu8.q8_plane / 2, 16, (const __bf16*)a.w2_8, a.w8_plane / 2, act, tt0, wave, lane, [&] { mark(9); });
+            mark(5);
+            i8_dequant_tile(q, acc, a.s_w2, a.relu8.q8_scale, wave * FT * 32, tok0, lane);
+        }
+        as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
+        EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
+        mark(6);
+        return;
+    }
+    if constexpr (!FFN8) {
     G::run(acc, a.ln1.out, a.ln1.out_plane, 32, a.w1, a.w1_plane, act, tt0, wave, lane, [&] { mark(8); });
     mark(3);
     a.relu.template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
@@ -291,6 +346,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
     EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
     mark(6);
+    }
 }
 
 // ---- embed and linear_out on the same operand path -----------------------------------------------------------------

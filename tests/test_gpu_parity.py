@@ -486,7 +486,7 @@ def test_ddim_eta1_full_chain_is_the_ddpm_chain(prec):
     assert (a - b).abs().max().item() < 3e-4, (a - b).abs().max().item()
     c = x0.clone()
     eng.ddim_loop_(c, xc, list(range(999, -1, -1)), eta=0.0)
-    assert (a - c).abs().max().item() > 1e-2  # eta matters
+    assert (a - c).abs().max().item() > 1e-3  # eta matters
     ts = sorted({int(round(v)) for v in np.linspace(0, 999, 12)}, reverse=True)
     nz = torch.randn(len(ts), B, T, 198, generator=g)
     d = x0.clone()

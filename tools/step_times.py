@@ -18,6 +18,8 @@ from egoego_release_amd.model import CondGaussianDiffusion  # noqa: E402
 
 
 def main():
+    if "EGOEGO_PERFDEBUG_TAG" in os.environ:  # time a variant build (build --perfdebug --tag=X -D...)
+        _lib.use_perfdebug_build()
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--batches", default="1,16,32,64,128,256")
