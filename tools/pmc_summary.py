@@ -9,7 +9,7 @@ from collections import defaultdict
 def short(name):
     m = re.match(r"void (\w+)<", name)
     base = m.group(1) if m else name.split("(")[0]
-    for tag in ("EpiEmbed", "EpiOut", "EpiQK") + (("EpiTiled", "EpiResLN") if "layer_tail" not in name else ()):
+    for tag in ("EpiEmbed", "EpiOut", "EpiQK") + (("EpiTiled", "EpiResLN") if "layer_tail" not in name else ()):  # (layer_tail*: one tag per kernel)
         if tag in name:
             base += ":" + tag
     return base

@@ -12,15 +12,16 @@ PEAK_TF, PEAK_I8, PEAK_HBM = 2500.0, 5000.0, 8.0  # TFLOP/s bf16 dense, TOP/s in
 ALG = {  # kernel tag -> (what, algorithmic FLOPs per launch, algorithmic HBM bytes per launch)
     "attn_layer_i8_kernel": ("Q/K/V projections + softmax + PV (one layer), int8 slices", B * (2 * L * DM * 3 * HD + 4 * L * L * HD),
                              2 * B * L * DM + 4 * B * L * HD + 3.2e6),
-    "layer_tail_kernel": ("fc+LN, FFN-1, FFN-2+LN (one layer)", B * L * (2 * HD * DM + 4 * DM * DM), 4 * B * L * (HD + DM + DM) + 4.2e6),
+    "layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; FFN on int8 slices in the i8x3 precision)", B * L * (2 * HD * DM + 4 * DM * DM), 4 * B * L * (HD + DM + DM) + 4.2e6),
     "EpiEmbed": ("embed GEMM + time token + pos-emb", 2 * B * T * 2 * D * DM, 4 * B * T * 2 * D + 4 * B * L * DM),
     "EpiOut": ("linear_out + DDPM posterior", 2 * B * T * DM * D, 4 * B * L * DM + 3 * 4 * B * T * D),
 }
 
 
 def main():
-    stats = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_b256_t120_kernel_stats.csv"))))
-    traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["kernels"]
+    rnd = os.environ.get("EGOEGO_ROUND", "r03")
+    stats = list(csv.DictReader(open(os.path.join(ROOT, "profiles", rnd + "_bench_b256_t120_kernel_stats.csv"))))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", rnd + "_traffic.json")))["kernels"]
     rows = []
     for tag, (what, flops, abytes) in ALG.items():
         st = next(r for r in stats if tag in r["Name"])
@@ -30,7 +31,7 @@ def main():
         peak = PEAK_I8 if "i8" in tag else PEAK_TF
         rows.append((tag, what, us, float(st["Percentage"]), flops / us / 1e6, flops / us / 1e6 / peak, 3 * flops / us / 1e6 / peak,
                      abytes / 1e6, (hbm or 0) / 1e6, (hbm or 0) / us / 1e6))
-    out = ["# Per-kernel roofline, round 2 (B=256, T=120, precision i8x3: int8-slice attention layer + split-bf16 elsewhere; from the files in this directory)", "",
+    out = [f"# Per-kernel roofline, round {int(rnd[1:])} (B=256, T=120, precision i8x3: int8-slice attention layer and FFN + split-bf16 elsewhere; from the files in this directory)", "",
            "MFMA bound: 2.5 PFLOP/s dense bf16, 5 POP/s dense int8; both split-bf16 and the int8 slices issue 3 MFMAs per algorithmic product, so the algorithmic fraction is capped at 33 %.",
            "HBM bound: 8 TB/s.  `traffic` = (2·FETCH_SIZE + WRITE_SIZE)·1024 from the PMC passes.", "",
            "| kernel | what | avg µs | % of GPU time | algorithmic TFLOP/s (TOP/s) | frac of the dtype's peak | MFMA-pipe frac (×3) | algorithmic MB | measured HBM MB | HBM TB/s |",
@@ -38,7 +39,7 @@ def main():
     for r in rows:
         out.append(f"| `{r[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.1f} | {r[4]:.0f} | {r[5]:.3f} | {r[6]:.3f} | {r[7]:.0f} | {r[8]:.0f} | {r[9]:.2f} |")
     text = "\n".join(out) + "\n"
-    open(os.path.join(ROOT, "profiles", "r02_roofline.md"), "w").write(text)
+    open(os.path.join(ROOT, "profiles", rnd + "_roofline.md"), "w").write(text)
     sys.stdout.write(text)
 
 

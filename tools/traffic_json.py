@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/r02_traffic.json.
+"""HBM bytes per launch per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/<round>_traffic.json (round tag: $EGOEGO_ROUND, default r03).
 
 usage: traffic_json.py <counter_collection.csv of the FETCH_SIZE pass> <... of the WRITE_SIZE pass> B T precision
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and FETCH_SIZE is doubled as
@@ -36,7 +36,7 @@ def main():
             continue
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         out["kernels"][k] = {"fetch_kb_raw": f, "write_kb": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    with open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w") as fh:
+    with open(os.path.join(ROOT, "profiles", os.environ.get("EGOEGO_ROUND", "r03") + "_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     for k, v in out["kernels"].items():
         print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch")
