@@ -432,10 +432,15 @@ template <int TT>
 static int launch_out_tt(const OutArgs& oa, int rows, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        HIP_TRY(allow_smem(out_kernel<TT>, TT * 32 * 1024));
+        HIP_TRY(allow_smem(out_kernel<TT, 1>, TT * 32 * 1024));
+        HIP_TRY(allow_smem(out_kernel<TT, 2>, TT * 32 * 1024));
         once = true;
     }
-    out_kernel<TT><<<dim3(rows / (32 * TT)), dim3(256), TT * 32 * 1024, s>>>(oa);
+    const int nb = rows / (32 * TT);
+    if (nb <= 128)  // fewer token blocks than half the CUs: two workgroups per token block, 128 features each
+        out_kernel<TT, 2><<<dim3(2 * nb), dim3(256), TT * 32 * 1024, s>>>(oa);
+    else
+        out_kernel<TT, 1><<<dim3(nb), dim3(256), TT * 32 * 1024, s>>>(oa);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -212,7 +212,8 @@ struct DirectGemm {
 
     template <class Mark>
     static EG_D void run(AccT (&acc)[FT][TT], const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, char* act,
-                         int tt0, int wave, int lane, Mark mark) {
+                         int tt0, int wave, int lane, Mark mark, int wtile0 = -1) {
+        const int wt0 = wtile0 >= 0 ? wtile0 : wave * FT;  // first weight row tile of this wave (default: FT consecutive tiles per wave)
         i32x4 wq[RING][NW];
         const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4), ir = tail_make_rsrc(in, in_plane * 4);
         const unsigned wpb = (unsigned)(w_plane * 2), ipb = (unsigned)(in_plane * 2);
@@ -221,7 +222,7 @@ struct DirectGemm {
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) out[2 * i + s] = s * wpb + (unsigned)(((wave * FT + i) * K16 + kb) << 10);
+                for (int s = 0; s < 2; ++s) out[2 * i + s] = s * wpb + (unsigned)(((wt0 + i) * K16 + kb) << 10);
         };
         auto dma_piece = [&](int q, int piece) {
             const int x = wave * DMA_PIECES + piece;  // flat index over [plane][t-tile][8 k-blocks]
@@ -381,12 +382,16 @@ struct OutArgs {
     size_t w_plane;
     EpiOut<2> epi;
 };
-template <int TT>
+// FS = 2: grids of at most 128 token blocks (half the CUs) split the 256 output features over two workgroups per token block
+// (a wave then owns 32 features): the posterior epilogue is elementwise, so nothing crosses the split.
+template <int TT, int FS>
 __global__ __launch_bounds__(256, 1) void out_kernel(OutArgs a) {
-    using G = DirectGemm<2, TT, 4>;
+    constexpr int FT = 2 / FS;
+    using G = DirectGemm<FT, TT, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
-    f32x16 acc[2][TT];
-    G::run(acc, a.h, a.h_plane, 32, a.w, a.w_plane, smem, (int)blockIdx.x * TT, wave, lane, [] {});
-    a.epi.template run<2, TT>(acc, wave * 64, (int)blockIdx.x * 32 * TT, lane, wave, 0, smem);
+    const int tb = (int)blockIdx.x / FS, fh = (int)blockIdx.x % FS;
+    f32x16 acc[FT][TT];
+    G::run(acc, a.h, a.h_plane, 32, a.w, a.w_plane, smem, tb * TT, wave, lane, [] {}, (fh * 4 + wave) * FT);
+    a.epi.template run<FT, TT>(acc, (fh * 4 + wave) * FT * 32, tb * 32 * TT, lane, wave, 0, smem);
 }
