@@ -268,10 +268,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void layer_tail_i8_kernel(GemmOpera
                                                                          GemmOperands g_2, const float* sw2, ELN e_2, int stop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tblk = (int)blockIdx.x + g_fc.tblk0;
+    // The per-feature parameters of the int8 epilogues (weight row scales of both convs, the first conv's bias) are staged
+    // behind the ring once: the epilogues read them tile by tile between fences, and an LDS read costs them a tenth of the
+    // L2 round trip.  Visible after the fc main loop's first barrier.
+    float* par = (float*)(smem + C::SMEM_BYTES);  // [3][512]: sw1, bias1, sw2
+    for (int i = threadIdx.x; i < 384; i += C::NT) {
+        const float* src = i < 128 ? sw1 + 4 * i : (i < 256 ? e_1.bias + 4 * (i - 128) : sw2 + 4 * (i - 256));
+        *(float4*)(par + 4 * i) = *(const float4*)src;
+    }
     GemmBody<C, ELN>::run(g_fc, e_fc, 0, tblk, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stop == 1) return;
+    ERQ e_1l = e_1;
+    e_1l.bias = par + 512;
     const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
     const int wf = wave % C::NWF, wt = wave / C::NWF;
     const int f0 = wf * C::FT * 32, t0 = (tblk * C::AT + wt * C::TT) * 32;
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void layer_tail_i8_kernel(GemmOpera
     {
         I8One q[C::FT][C::TT];
         i8_gemm(g_1, q);
-        e_1.template run<I8One, C::FT, C::TT>(q, sw1, e_fc.q8_scale, f0, t0, lane, wf, wt, smem);
+        e_1l.template run<true, I8One, C::FT, C::TT>(q, par, e_fc.q8_scale, f0, t0, lane, wf, wt, smem);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void layer_tail_i8_kernel(GemmOpera
         I8One q[C::FT][C::TT];
         i8_gemm(g_2, q);
         f32x16 acc[C::FT][C::TT];
-        i8_dequant_tile(q, acc, sw2, e_1.q8_scale, f0, t0, lane);
+        i8_dequant_tile<true>(q, acc, par + 1024, e_1.q8_scale, f0, t0, lane);
         e_2.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
     }
 }
@@ -656,11 +666,11 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             static_assert(CfgT8a::SMEM_BYTES <= CfgBs<2>::SMEM_BYTES && CfgT8b::SMEM_BYTES <= CfgBs<2>::SMEM_BYTES, "the int8 passes reuse the split-bf16 ring");
             static bool once = false;
             if (!once) {
-                HIP_TRY(allow_smem(kern, CfgBs<NP>::SMEM_BYTES));
+                HIP_TRY(allow_smem(kern, CfgBs<NP>::SMEM_BYTES + 6144));
                 once = true;
             }
             const int stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
-            kern<<<dim3(nb), dim3(CfgBs<NP>::NT), CfgBs<NP>::SMEM_BYTES, s>>>(g1, e1, g2, L.s_1, e2, g3, L.s_2, e3, stop);
+            kern<<<dim3(nb), dim3(CfgBs<NP>::NT), CfgBs<NP>::SMEM_BYTES + 6144, s>>>(g1, e1, g2, L.s_1, e2, g3, L.s_2, e3, stop);
             HIP_TRY(hipGetLastError());
             if (last_dbg) return 0;
             continue;

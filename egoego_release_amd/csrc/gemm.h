@@ -440,7 +440,8 @@ EG_D void i8_dequant(const I8One& q, f32x16& o, const float* sw8, float sa) {
 }
 // A whole wave tile: acc[i][j] = dequantised sums of feature tile i (weight row scales sw[f0 + 32 i ..]) and token tile j
 // (activation row scales sa[t0 + 32 j + col]); what an fp32 epilogue (EpiResLN, EpiReluQ8) then takes.
-template <class QT, int FT, int TT>
+// FENCE: for waves with 256 registers (two per SIMD) — see below; a 512-register wave lets hipcc batch all the loads.
+template <bool FENCE, class QT, int FT, int TT>
 EG_D void i8_dequant_tile(const QT (&q)[FT][TT], f32x16 (&acc)[FT][TT], const float* sw, const float* sa, int f0, int t0, int lane) {
     const int hf = lane >> 5, col = lane & 31;
     float s[TT];
@@ -450,13 +451,17 @@ EG_D void i8_dequant_tile(const QT (&q)[FT][TT], f32x16 (&acc)[FT][TT], const fl
     // hipcc from hoisting every tile's scale loads to the top, which costs more registers than the wave has
 #pragma unroll
     for (int i = 0; i < FT; ++i) {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if (FENCE) {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < TT; ++j) i8_dequant(q[i][j], acc[i][j], sw + f0 + i * 32 + 4 * hf, s[j]);
     }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);  // ... and the epilogue's loads from moving up beside the still-live integer sums
+    if (FENCE) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);  // ... and the epilogue's loads from moving up beside the still-live integer sums
+    }
 }
 // un-swapped accumulator (lane owns a feature, registers walk tokens)
 EG_D void i8_dequant_rows(const I8Acc& q, f32x16& o, float sw, const float* sa8) {
@@ -522,11 +527,13 @@ struct EpiReluQ8 {
     size_t q8_plane;
     float* q8_scale;     // [Mp]
     // q: the integer sums of an int8-slice contraction (I8Acc or I8One); sw / sa: weight-row and activation-row scales.
-    // Two sweeps over the INTEGER sums, one tile at a time (a tile's 16 scales and 16 biases in registers; the fences keep
-    // hipcc from hoisting every tile's loads to the top): the first only takes the row maximum of relu(dequant + bias),
-    // the second recomputes those values and quantises them straight into the stores.  No fp32 copy of the wave tile
-    // ever exists, which is what lets a 256-register wave (128 of them integer sums) run this without spilling.
-    template <class QT, int FT, int TT>
+    // LEAN (256-register waves, two per SIMD): two sweeps over the INTEGER sums, one tile at a time (a tile's 16 scales and
+    // 16 biases in registers; the fences keep hipcc from hoisting every tile's loads to the top): the first only takes the
+    // row maximum of relu(dequant + bias), the second recomputes those values and quantises them straight into the
+    // stores — no fp32 copy of the wave tile ever exists, which is what lets such a wave (128 registers of integer sums)
+    // run this without spilling.  !LEAN (512-register waves, one per SIMD, every load latency exposed): one sweep, the
+    // values kept, all parameter loads in flight at once.  Same float operations per value: same bits.
+    template <bool LEAN, class QT, int FT, int TT>
     __device__ void run(const QT (&q)[FT][TT], const float* sw, const float* sa, int f0, int t0, int lane, int wf, int wt, char* smem) const {
         static_assert(NWF * FT * 32 == 512, "the row maximum needs the whole 512-wide row in the block");
         const int hf = lane >> 5, col = lane & 31;
@@ -547,16 +554,20 @@ struct EpiReluQ8 {
                 for (int c = 0; c < 4; ++c) v[4 * g + c] = fmaxf(v[4 * g + c] + bb[c], 0.f);
             }
         };
+        f32x16 keep[LEAN ? 1 : FT][LEAN ? 1 : TT];
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j) {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                if (LEAN) {
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 f32x16 v;
                 tile(i, j, v);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) amax[j] = fmaxf(amax[j], v[r]);
+                if (!LEAN) keep[LEAN ? 0 : i][LEAN ? 0 : j] = v;
             }
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
@@ -577,10 +588,14 @@ struct EpiReluQ8 {
         for (int i = 0; i < FT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j) {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
                 f32x16 v;
-                tile(i, j, v);
+                if (LEAN) {
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    tile(i, j, v);
+                } else {
+                    v = keep[LEAN ? 0 : i][LEAN ? 0 : j];
+                }
                 float t[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t[r] = v[r];

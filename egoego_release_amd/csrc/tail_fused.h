@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
             I8Acc q[FT][TT];
             G8::run(q, (const __bf16*)a.ln1.q8, a.ln1.q8_plane / 2, 16, (const __bf16*)a.w1_8, a.w8_plane / 2, act, tt0, wave, lane, [&] { mark(8); });
             mark(3);
-            e8.template run<I8Acc, FT, TT>(q, a.s_w1, a.ln1.q8_scale, wave * FT * 32, tok0, lane, wave, 0, red);
+            e8.template run<false, I8Acc, FT, TT>(q, a.s_w1, a.ln1.q8_scale, wave * FT * 32, tok0, lane, wave, 0, red);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
             I8Acc q[FT][TT];
             G8::run(q, (const __bf16*)a.relu8.q8, a.relu8.q8_plane / 2, 16, (const __bf16*)a.w2_8, a.w8_plane / 2, act, tt0, wave, lane, [&] { mark(9); });
             mark(5);
-            i8_dequant_tile(q, acc, a.s_w2, a.relu8.q8_scale, wave * FT * 32, tok0, lane);
+            i8_dequant_tile<false>(q, acc, a.s_w2, a.relu8.q8_scale, wave * FT * 32, tok0, lane);
         }
         as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
         EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
