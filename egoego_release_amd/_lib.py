@@ -13,7 +13,7 @@ ABI_VERSION = 3
 FLAG_NO_GRAPH = 1
 PRED_NOISE, PRED_X0 = 0, 1
 NOISE_INJECTED, NOISE_PHILOX, NOISE_NONE = 0, 1, 2
-PREC_BF16X3, PREC_BF16X1, PREC_I8X3 = 3, 1, 8
+PREC_BF16X3, PREC_BF16X1, PREC_I8X3, PREC_I8X3_FC = 3, 1, 8, 9
 K_QKV, K_ATTN, K_FC_LN, K_FFN1, K_FFN2_LN, K_EMBED, K_OUT = range(7)
 KERNEL_NAMES = {"qkv": K_QKV, "attn": K_ATTN, "fc_ln": K_FC_LN, "ffn1": K_FFN1, "ffn2_ln": K_FFN2_LN,
                 "embed": K_EMBED, "out": K_OUT}

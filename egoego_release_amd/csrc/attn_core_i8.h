@@ -180,6 +180,10 @@ struct AttnCore8Args {
     __bf16* o;  // [Mp][HD] split-bf16 fragment-tiled (accumulator order): the fc GEMM's operand
     size_t o_plane;
     int HD16, H, L, Lp;
+    // o8 != nullptr: O as int8 slices with one scale per row and head (see AttnLayerArgs)
+    int8_t* o8;
+    size_t o8_plane;
+    float* o_scale;
 };
 
 // The K image (d_k halves) and the V^T image (d_v halves) pass through two LDS buffers of KT * 8 KiB x 2 slices each, the next
@@ -323,7 +327,9 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
 
     // ---- O^T = V^T P (TM:83-88) per d_v half, heads merged on store
     const int m = b * a.Lp + qt * 32 + col;
-#pragma unroll 1
+    float t8[8][16];  // int8 output: the first half's values wait for the row maximum over the head's 256 features
+    float amax = 0.f;
+#pragma unroll
     for (int dvh = 0; dvh < 2; ++dvh) {
         // this half has landed: all pieces of half 0 were issued before those of half 1 (loads return in order)
         if (dvh == 0) wait_counts<NPIECE, 15>(); else wait_counts<0, 15>();
@@ -348,7 +354,16 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps1[kb], o[dt].h, 0, 0, 0);
         }
-        if (active) {
+        if (a.o8) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = (float)i8_combine(o[dt].h[r], o[dt].m[r]) * oscale;
+                    t8[dvh * 4 + dt][r] = v;
+                    amax = fmaxf(amax, fabsf(v));
+                }
+        } else if (active) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int tile = dvh * 4 + dt;
@@ -364,6 +379,19 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
                     *(u32x4*)(a.o + a.o_plane + idx) = lo;
                 }
             }
+        }
+    }
+    if (a.o8 && active) {
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        const float inv = amax > 0.f ? I8_QMAX / amax : 0.f;
+        if (hf == 0) a.o_scale[(size_t)m * a.H + h] = amax > 0.f ? amax / I8_QMAX : 0.f;
+#pragma unroll
+        for (int tile = 0; tile < 8; ++tile) {
+            u32x4 s1, s2;
+            quant16(t8[tile], inv, s1, s2);
+            const size_t idx = acc_slot_i8(m, h * 256 + tile * 32, hf, a.HD16 / 2);
+            *(u32x4*)(a.o8 + idx) = s1;
+            *(u32x4*)(a.o8 + a.o8_plane + idx) = s2;
         }
     }
 }

@@ -34,6 +34,11 @@ struct AttnLayerArgs {
     float qscale;
     int H, L, bh0;
     EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][16] phase timestamps or nullptr
+    // o8 != nullptr: O goes out as int8 slices instead ([Mp][HD] fragment-tiled, K in acc32 order, slices o8_plane bytes
+    // apart) with one scale per row AND head, o_scale[row * H + head] — the operand of the int8 fc contraction
+    int8_t* o8;
+    size_t o8_plane;
+    float* o_scale;
 };
 
 using AL8K = GemmCfg<4, 2, 2, 2, 1, 2, false, 1, 3>;
@@ -291,9 +296,7 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
     // ---- 5. O^T = V^T P (TM:83-88), heads merged on store ------------------------------------------------
     const int m = b * 128 + wave * 32 + col;
     const float oscale = rsum * (256.0f / I8_QMAX);
-#pragma unroll 1
-    for (int dvh = 0; dvh < 2; ++dvh) {
-        I8Acc o[4];
+    auto pv_half = [&](int dvh, I8Acc (&o)[4]) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) acc_zero(o[dt]);
 #pragma unroll
@@ -312,27 +315,71 @@ __global__ __launch_bounds__(256, 1) void attn_layer_i8_kernel(AttnLayerArgs a) 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps1[kb], o[dt].h, 0, 0, 0);
         }
+    };
+    // fp32 value of accumulator register r of d_v tile `tile`
+    auto o_val = [&](const I8Acc& o, int tile, int g, float (&t)[4]) {
+        const float4 s4 = *(const float4*)(sv + tile * 32 + 8 * g + 4 * hf);
+        const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int tile = dvh * 4 + dt;
+        for (int c = 0; c < 4; ++c) t[c] = (float)i8_combine(o.h[4 * g + c], o.m[4 * g + c]) * (ss[c] * oscale);
+    };
+    if (a.o8) {
+        // int8 rows for the int8 fc: a lane holds all 256 d_v of its query over the two halves, so the row maximum of this
+        // head is in-lane + one cross-half shuffle; the first half's values wait in registers for it
+        float t[8][16];
+        float amax = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                float t[8];
+        for (int dvh = 0; dvh < 2; ++dvh) {
+            I8Acc o[4];
+            pv_half(dvh, o);
 #pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    const float4 s4 = *(const float4*)(sv + tile * 32 + 8 * (2 * jj + g2) + 4 * hf);
-                    const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    o_val(o[dt], dvh * 4 + dt, g, v);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const int r = 8 * jj + 4 * g2 + c;
-                        t[4 * g2 + c] = (float)i8_combine(o[dt].h[r], o[dt].m[r]) * (ss[c] * oscale);
+                        t[dvh * 4 + dt][4 * g + c] = v[c];
+                        amax = fmaxf(amax, fabsf(v[c]));
                     }
                 }
-                u32x4 hi, lo;
-                split8(t, hi, lo);
-                const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
-                *(u32x4*)(a.o + idx) = hi;
-                *(u32x4*)(a.o + a.o_plane + idx) = lo;
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        const float inv = amax > 0.f ? I8_QMAX / amax : 0.f;
+        if (hf == 0) a.o_scale[(size_t)m * a.H + h] = amax > 0.f ? amax / I8_QMAX : 0.f;
+#pragma unroll
+        for (int tile = 0; tile < 8; ++tile) {
+            u32x4 s1, s2;
+            quant16(t[tile], inv, s1, s2);
+            const size_t idx = acc_slot_i8(m, h * 256 + tile * 32, hf, a.HD16 / 2);
+            *(u32x4*)(a.o8 + idx) = s1;
+            *(u32x4*)(a.o8 + a.o8_plane + idx) = s2;
+        }
+    } else {
+#pragma unroll 1
+        for (int dvh = 0; dvh < 2; ++dvh) {
+            I8Acc o[4];
+            pv_half(dvh, o);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int tile = dvh * 4 + dt;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    float t[8];
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        float v[4];
+                        o_val(o[dt], tile, 2 * jj + g2, v);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) t[4 * g2 + c] = v[c];
+                    }
+                    u32x4 hi, lo;
+                    split8(t, hi, lo);
+                    const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
+                    *(u32x4*)(a.o + idx) = hi;
+                    *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                }
             }
         }
     }

@@ -50,6 +50,8 @@ struct LayerDev {
     float* s_qkv;                      // its row scales [3*HD]
     int8_t *w_1_8, *w_2_8;             // i8x3 copies of the FFN weights: two slices of [512][512], K in acc32 order
     float *s_1, *s_2;                  // their row scales [512]
+    int8_t* w_fc_8;                    // i8x3 copy of w_fc: two slices of [512][HD]
+    float* s_fc;                       // its row scales [512]
     float *b_qkv, *b_fc, *ln1_g, *ln1_b, *b_1, *b_2, *ln2_g, *ln2_b;
 };
 
@@ -96,6 +98,8 @@ struct egoego_ctx {
 };
 
 static const int N_MODEL = 512;
+// the int8-slice precisions: EGOEGO_PREC_I8X3 (attention layer + FFN) and EGOEGO_PREC_I8X3_FC (the same + fc)
+static inline bool prec_i8(const egoego_ctx* c) { return c->cfg.precision == EGOEGO_PREC_I8X3 || c->cfg.precision == EGOEGO_PREC_I8X3_FC; }
 #ifdef EGOEGO_PERFDEBUG
 // perf-debug build only (tools/*_trace.py): per-block timestamps and stage ablation, set through egoego_debug_*
 static unsigned long long* g_trace = nullptr;
@@ -138,6 +142,8 @@ struct Workspace {
     float* hA_scale;  // [Mp]
     int8_t *hB8, *F8;           // i8x3 FFN: LayerNorm-1 output and ReLU output as int8 slices (same layout as hA8)
     float *hB_scale, *F_scale;  // [Mp] their row scales
+    int8_t* O8;                 // i8x3 fc: the attention output as int8 slices, slice stride o_plane bytes
+    float* O_scale;             // [Mp][H] one scale per row and head
     float *sq8, *sk8, *sv8;  // [B*H][Lp] row scales of the int8 Q / K / V images (attn_core_i8.h; the images alias Q, K, V)
     size_t total;
 };
@@ -172,6 +178,8 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
     w.hB_scale = (float*)take(sizeof(float) * g.Mp);
     w.F8 = (int8_t*)take(2 * w.h_plane);
     w.F_scale = (float*)take(sizeof(float) * g.Mp);
+    w.O8 = (int8_t*)take(2 * w.o_plane);
+    w.O_scale = (float*)take(sizeof(float) * (size_t)g.Mp * c->H);
     w.sq8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
     w.sk8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
     w.sv8 = (float*)take(sizeof(float) * (size_t)g.B * c->H * g.Lp);
@@ -409,18 +417,28 @@ template <bool FFN8>
 static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        HIP_TRY(allow_smem(tail_kernel<2, FFN8>, tail_smem_bytes(2)));
-        HIP_TRY(allow_smem(tail_kernel<1, FFN8>, tail_smem_bytes(1)));
+        HIP_TRY(allow_smem((tail_kernel<2, FFN8, false>), tail_smem_bytes(2)));
+        HIP_TRY(allow_smem((tail_kernel<1, FFN8, false>), tail_smem_bytes(1)));
         once = true;
     }
     if (rows / 64 >= 256)
-        tail_kernel<2, FFN8><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
+        tail_kernel<2, FFN8, false><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
     else
-        tail_kernel<1, FFN8><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+        tail_kernel<1, FFN8, false><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
+    if (ta.fc8) {  // int8 fc: 32-token workgroups only (64-token ones need more than 512 registers per lane)
+        static bool once = false;
+        if (!once) {
+            HIP_TRY(allow_smem((tail_kernel<1, true, true>), tail_smem_bytes(1)));
+            once = true;
+        }
+        tail_kernel<1, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     return ta.ffn8 ? launch_tail_f<true>(ta, rows, s) : launch_tail_f<false>(ta, rows, s);
 }
 
@@ -507,7 +525,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     // --- embed: start_conv + time token + position embedding (TM:199-216)
     // i8x3: windows of 65..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
     // layer reads the embed output as int8 rows
-    const bool i8_path = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;  // every layer input also as int8 rows
+    const bool i8_path = NP == 2 && prec_i8(c);  // every layer input also as int8 rows
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
         if (NP == 2 && direct_embed) {
@@ -537,8 +555,11 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         AttnArgs aa{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L, w0 * H};
         // the fused kernel has one workgroup per (window, head): below ~one workgroup per CU the unfused pair
         // (12 projection blocks per window) spreads the same work over more CUs
-        const bool i8 = NP == 2 && c->cfg.precision == EGOEGO_PREC_I8X3;
+        const bool i8 = NP == 2 && prec_i8(c);
         const bool ffn8 = i8;  // i8x3: the FFN contractions run on int8 slices too (every batch size: same integers, same bits)
+        // EGOEGO_PREC_I8X3_FC: fc as well, where the attention kernel can hand O over as int8 rows (the two int8 attention back
+        // ends: windows of more than 64 tokens); the Q/K/V debug stops run the split-bf16 projections and never reach fc
+        const bool fc8 = i8 && c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7);
         const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && (i8 || nw * H >= 192);
         const bool fused_attn = attn_geom && !dbg_qkv;
         // the layer's output also as int8 slices: the next layer's projections consume them
@@ -548,6 +569,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             ProfScope ps(c, EGOEGO_K_QKV, s);
             AttnLayerArgs al{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, L.b_qkv, w.hA8, w.h_plane, w.hA_scale, w.O, w.o_plane, HD / 16,
                              1.0f / sqrtf((float)c->cfg.d_k), H, g.L, w0 * H EG_DBG(, g_trace)};
+            if (fc8) {
+                al.o8 = w.O8; al.o8_plane = w.o_plane; al.o_scale = w.O_scale;
+            }
             static bool once = false;
             if (!once) {
                 HIP_TRY(allow_smem(attn_layer_i8_kernel, AL_SMEM_BYTES));
@@ -591,6 +615,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     ProfScope ps(c, EGOEGO_K_ATTN, s);
                     AttnCore8Args ca{(const int8_t*)w.Q, (const int8_t*)w.K, (const int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, w.O, w.o_plane,
                                      HD / 16, H, g.L, g.Lp};
+                    if (fc8) {
+                        ca.o8 = w.O8; ca.o8_plane = w.o_plane; ca.o_scale = w.O_scale;
+                    }
                     if (int r = launch_attn_core8(ca, g.KT, g.B * H, s)) return r;
                 }
             } else if (i8 && !dbg_qkv) {
@@ -626,13 +653,20 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         }
         if (last_dbg && io.stop_stage == EGOEGO_DBG_ATTN_OUT) return 0;
         if constexpr (NP == 2) {
-            if (tb_b <= 128) {
+            // int8 fc: the 512-register direct-operand kernel at EVERY batch size (its per-head fp32 running sums next to the
+            // integer accumulators do not fit a 256-register wave)
+            if (tb_b <= 128 || fc8) {
                 // --- small batches (at most one 64-token workgroup per CU): fc+LN -> FFN-1 -> FFN-2+LN in one latency-optimised kernel (tail_fused.h), same arithmetic
                 ProfScope ps(c, EGOEGO_K_FC_LN, s);
                 TailArgs ta{};
                 ta.o = w.O; ta.o_plane = w.o_plane; ta.HD16 = HD / 16;
                 ta.wfc = L.w_fc; ta.wfc_plane = (size_t)N_MODEL * HD;
                 ta.ln1 = EpiResLN<2, 4, 0>{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f, nullptr, 0, nullptr};
+                if (fc8) {
+                    ta.fc8 = 1; ta.H = H;
+                    ta.o8 = w.O8; ta.o8_plane = w.o_plane; ta.o_scale = w.O_scale;
+                    ta.wfc8 = L.w_fc_8; ta.wfc8_plane = (size_t)N_MODEL * HD; ta.s_wfc = L.s_fc;
+                }
                 if (ffn8) {  // FFN on int8 slices: LayerNorm-1 also emits int8 rows, FFN-1 writes int8 rows
                     ta.ffn8 = 1;
                     ta.ln1.q8 = w.hB8; ta.ln1.q8_plane = w.h_plane; ta.ln1.q8_scale = w.hB_scale;
@@ -835,7 +869,8 @@ int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
     if (cfg->max_timesteps < 2 || cfg->num_timesteps < 1) return fail(EGOEGO_E_INVALID, "bad max_timesteps/num_timesteps");
     if (cfg->objective != EGOEGO_PRED_X0 && cfg->objective != EGOEGO_PRED_NOISE)
         return fail(EGOEGO_E_INVALID, "unknown objective %d", cfg->objective);
-    if (cfg->precision != EGOEGO_PREC_BF16X3 && cfg->precision != EGOEGO_PREC_BF16X1 && cfg->precision != EGOEGO_PREC_I8X3)
+    if (cfg->precision != EGOEGO_PREC_BF16X3 && cfg->precision != EGOEGO_PREC_BF16X1 && cfg->precision != EGOEGO_PREC_I8X3 &&
+        cfg->precision != EGOEGO_PREC_I8X3_FC)
         return fail(EGOEGO_E_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->flags & ~EGOEGO_FLAG_NO_GRAPH) return fail(EGOEGO_E_INVALID, "unknown flags 0x%x", cfg->flags);
     int ndev = 0;
@@ -968,6 +1003,9 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
         if ((r = dev_alloc(c, (void**)&L.w_2_8, (size_t)2 * N_MODEL * N_MODEL, false, s))) return r;
         if ((r = dev_alloc(c, (void**)&L.s_1, sizeof(float) * N_MODEL, false, s))) return r;
         if ((r = dev_alloc(c, (void**)&L.s_2, sizeof(float) * N_MODEL, false, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.w_fc_8, (size_t)2 * N_MODEL * HD, false, s))) return r;
+        if ((r = dev_alloc(c, (void**)&L.s_fc, sizeof(float) * N_MODEL, false, s))) return r;
+        k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_fc, HD, HD, L.w_fc_8, (size_t)N_MODEL * HD, L.s_fc, 0);
         k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_1, N_MODEL, N_MODEL, L.w_1_8, (size_t)N_MODEL * N_MODEL, L.s_1, 0);
         k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_2, N_MODEL, N_MODEL, L.w_2_8, (size_t)N_MODEL * N_MODEL, L.s_2, 0);
         HIP_TRY(hipGetLastError());
@@ -1367,13 +1405,16 @@ int egoego_debug_stage(egoego_ctx* c, const float* d_x, const float* d_xc, const
             k_unpack_tiled<<<2048, 256, 0, s>>>(w.hB, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_FFN_HIDDEN:
-            if (c->cfg.precision == EGOEGO_PREC_I8X3)  // the hidden activations exist as int8 rows only
-                k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.F8, w.h_plane, w.F_scale, N_MODEL, g.Lp, L, B, d_out);
+            if (prec_i8(c))  // the hidden activations exist as int8 rows only
+                k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.F8, w.h_plane, w.F_scale, N_MODEL, g.Lp, L, B, d_out, 1);
             else
                 k_unpack_tiled<<<2048, 256, 0, s>>>(w.F, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_ATTN_OUT:
-            k_unpack_tiled<<<2048, 256, 0, s>>>(w.O, w.o_plane, c->HD, g.Lp, L, B, d_out, lo);
+            if (c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7))  // int8 rows, one scale per row and head
+                k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.O8, w.o_plane, w.O_scale, c->HD, g.Lp, L, B, d_out, c->H);
+            else
+                k_unpack_tiled<<<2048, 256, 0, s>>>(w.O, w.o_plane, c->HD, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_Q:
             k_unpack_qk<<<2048, 256, 0, s>>>(w.Q, w.qkv_plane, c->H, g.Lp, L, B, d_out, lo);

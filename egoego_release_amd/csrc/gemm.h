@@ -44,6 +44,7 @@ struct GemmOperands {
     int tblk0;  // first token block of this launch (window-chunked launches)
     EG_DBG(int ablate;                  // 2 = skip the epilogue, 4 = skip attention
            unsigned long long* trace;)  // [nblocks][4] = {t_start, t_mainloop_end, t_end, hw_id | xcc_id << 32} or nullptr
+    int kcount;  // k-blocks to contract, starting at w / a (K16 stays the row stride of both operands); 0 = all K16
 };
 
 // Blocks that share an activation tile (same token block, different feature blocks) are made
@@ -182,7 +183,7 @@ struct GemmBody {
                 for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
         }
 
-        const int ns = g.K16 / KS;
+        const int ns = (g.kcount ? g.kcount : g.K16) / KS;
         // ---- software pipeline -------------------------------------------------------------------
         // Ring of NS LDS stages filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight
         // into the fragment-tiled image at wave-uniform base + 16*lane; no VGPR staging, no ds_write).
@@ -472,6 +473,24 @@ EG_D void i8_dequant_rows(const I8Acc& q, f32x16& o, float sw, const float* sa8)
         const float as[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[4 * g + c] = (float)i8_combine(q.h[4 * g + c], q.m[4 * g + c]) * (sw256 * as[c]);
+    }
+}
+
+// ---- int8 contraction whose activation rows carry one scale per K CHUNK (the attention output: one scale per row and head,
+// K = H x 256).  Each chunk is its own exact integer chain; chunk by chunk the sums are folded into an fp32 running sum,
+//     run <- fma(float(I_chunk), 256 * s_act[row, chunk], run)      (chunks in ascending order, run = 0 before the first)
+// and the weight row scale is applied once at the end.  Both tail kernels call exactly these two functions.
+EG_D void i8_fold(const I8Acc& q, f32x16& run, float sa256) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) run[r] = __builtin_fmaf((float)i8_combine(q.h[r], q.m[r]), sa256, run[r]);
+}
+EG_D void i8_fold_finish(f32x16& run, const float* sw8) {  // sw8 = weight row scales + first feature of the tile + 4 * hf
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w4 = *(const float4*)(sw8 + 8 * g);
+        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) run[4 * g + c] *= ws[c];
     }
 }
 

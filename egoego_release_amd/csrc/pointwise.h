@@ -438,17 +438,18 @@ __global__ void k_unpack_tiled(const __bf16* __restrict__ src, size_t plane, int
     }
 }
 
-// int8-slice rows [Mp][N] (K in acc32 order, one scale per row) -> fp32 [B][L][N].
+// int8-slice rows [Mp][N] (K in acc32 order; `groups` scales per row, each covering N / groups consecutive columns) -> fp32 [B][L][N].
 __global__ void k_unpack_rows_i8(const int8_t* __restrict__ src, size_t plane, const float* __restrict__ scale, int N, int Lp, int L, int B,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, int groups) {
     const size_t n = (size_t)B * L * N;
+    const int gw = N / groups;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int f = (int)(i % N);
         const size_t bl = i / N;
         const int l = (int)(bl % L), b = (int)(bl / L);
         const int m = b * Lp + l;
         const size_t idx = tiled_index_i8(m, acc32(f), N >> 5);
-        out[i] = (float)((int)src[idx] * 256 + (int)src[plane + idx]) * scale[m];
+        out[i] = (float)((int)src[idx] * 256 + (int)src[plane + idx]) * scale[(size_t)m * groups + f / gw];
     }
 }
 

@@ -44,6 +44,16 @@ struct TailArgs {
     const __bf16* w2;
     size_t w2_plane;
     EpiResLN<2, 4, 0> ln2;   // bias, residual hb, gamma/beta, row mask, output (+ optional int8 copy)
+    // i8x3 fc (fc8 != 0; windows of more than 64 tokens, whose attention kernels write O as int8 rows): the attention output as
+    // int8 slices with one scale per row and head, w_fc as int8 slices with one scale per output row; one exact integer
+    // chain per head (8 k-blocks = one chunk), folded into an fp32 running sum (gemm.h i8_fold)
+    int fc8, H;
+    const int8_t* o8;        // [Mp][HD] two slices, o8_plane BYTES apart
+    size_t o8_plane;
+    const float* o_scale;    // [Mp][H]
+    const int8_t* wfc8;      // [512][HD] two slices, wfc8_plane BYTES apart
+    size_t wfc8_plane;
+    const float* s_wfc;      // [512]
     // i8x3 FFN (ffn8 != 0): w_1 / w_2 as int8 slices with one scale per output row; LayerNorm-1 also emits int8 rows (ln1.q8),
     // FFN-1 writes the ReLU output as int8 rows (relu8) and FFN-2 reads them
     int ffn8;
@@ -210,9 +220,13 @@ struct DirectGemm {
     static constexpr int DMA_PIECES = 4 * TT;                                // 1-KiB pieces of a chunk per wave
     static constexpr int SMEM_BYTES = 2 * CH_BYTES;
 
-    template <class Mark>
+    struct NoPost {
+        EG_D void operator()(int) const {}
+    };
+    // post(q): called after the MFMAs of chunk q (8 k-blocks), e.g. to fold a chunk's integer sums away (int8 fc)
+    template <class Mark, class Post = NoPost>
     static EG_D void run(AccT (&acc)[FT][TT], const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, char* act,
-                         int tt0, int wave, int lane, Mark mark, int wtile0 = -1) {
+                         int tt0, int wave, int lane, Mark mark, int wtile0 = -1, Post post = Post{}) {
         const int wt0 = wtile0 >= 0 ? wtile0 : wave * FT;  // first weight row tile of this wave (default: FT consecutive tiles per wave)
         i32x4 wq[RING][NW];
         const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4), ir = tail_make_rsrc(in, in_plane * 4);
@@ -253,12 +267,14 @@ struct DirectGemm {
             w_offsets(8 * q + 8, wnext);
             TailChunk<FT, TT, RING, false, DMA_PIECES, 8, I8>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
                                                              [&](int piece) { dma_piece(q + 1, piece); });
+            post(q);
             // the next chunk has landed (counted wait inside run) and everyone is done with this one
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
         w_offsets(8 * (NQ - 1), wcur);
         TailChunk<FT, TT, RING, true, 0, (REM2 ? 2 : 8), I8>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
+        post(NQ - 1);
         __syncthreads();  // every wave is done with the chunk buffers before the next GEMM's first DMA
     }
 };
@@ -266,9 +282,9 @@ struct DirectGemm {
 // (Measured and NOT kept for B = 256: the same kernel with 2 ring slots, 256 registers and two co-resident 64-token workgroups per
 // CU — 278 us per launch against the 222 us of layer_tail_kernel, and no better with the second half of the grid started 20-80 us
 // late: a LayerNorm epilogue that takes 13 us alone takes 60 us next to a wave that saturates the matrix pipe of the same SIMD.)
-// FFN8: the two FFN contractions on int8 slices (TailArgs::ffn8 ...; the i8x3 precision) — a separate instantiation, so
-// that the split-bf16 kernel's register allocation is untouched.
-template <int TT, bool FFN8>
+// FFN8: the two FFN contractions on int8 slices (TailArgs::ffn8 ...; the i8x3 precision); FC8: fc too (TailArgs::fc8 ...) —
+// separate instantiations, so that the split-bf16 kernel's register allocation is untouched.
+template <int TT, bool FFN8, bool FC8 = false>
 __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     constexpr int TOK = 32 * TT, FT = 4;
     using G = DirectGemm<FT, TT, 4>;
@@ -295,7 +311,36 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     };
 
     // =============================================================== 1. fc + residual + LayerNorm (TM:92-93, 135)
-    G::run(acc, a.o, a.o_plane, a.HD16, a.wfc, a.wfc_plane, act, tt0, wave, lane, [&] { mark(7); });
+    if constexpr (FC8) {
+        using GF = DirectGemm<FT, TT, (TT == 2 ? 2 : 4), false, true>;
+        I8Acc q[FT][TT];
+        float so[TT];
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int col = lane & 31;
+        GF::run(q, (const __bf16*)a.o8, a.o8_plane / 2, a.HD16 / 2, (const __bf16*)a.wfc8, a.wfc8_plane / 2, act, tt0, wave, lane, [&] { mark(7); }, -1,
+                [&](int h) {  // head h's chain is complete: fold it into the running sum and start the next one from zero
+#pragma unroll
+                    for (int j = 0; j < TT; ++j) so[j] = a.o_scale[(size_t)(tok0 + j * 32 + col) * a.H + h] * 256.0f;
+#pragma unroll
+                    for (int i = 0; i < FT; ++i)
+#pragma unroll
+                        for (int j = 0; j < TT; ++j) {
+                            i8_fold(q[i][j], acc[i][j], so[j]);
+                            acc_zero(q[i][j]);
+                        }
+                });
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) i8_fold_finish(acc[i][j], a.s_wfc + wave * FT * 32 + i * 32 + 4 * (lane >> 5));
+    } else {
+        G::run(acc, a.o, a.o_plane, a.HD16, a.wfc, a.wfc_plane, act, tt0, wave, lane, [&] { mark(7); });
+    }
     mark(1);
     as_ln(a.ln1).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
     // this workgroup's LayerNorm-1 rows must have reached L2 before its LDS-DMAs of them

@@ -17,7 +17,7 @@ def _f32c(t, device):
 
 
 class HipEngine:
-    def __init__(self, cfg_dict, state_dict, device, precision=_lib.PREC_I8X3, flags=0):
+    def __init__(self, cfg_dict, state_dict, device, precision=_lib.PREC_I8X3_FC, flags=0):
         """cfg_dict: d_feats, d_model, n_head, n_dec_layers, d_k, d_v, max_timesteps, num_timesteps,
         objective ('pred_x0' | 'pred_noise').  state_dict: reference-layout tensors (any device)."""
         self.lib = _lib.load()

@@ -55,9 +55,13 @@ enum { EGOEGO_PRED_NOISE = 0, EGOEGO_PRED_X0 = 1 };        /* M:235-240 */
 enum { EGOEGO_NOISE_INJECTED = 0, EGOEGO_NOISE_PHILOX = 1, EGOEGO_NOISE_NONE = 2 };
 /* operand precision of every contraction: 3 = split-bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate;
  * meets the 1e-3 parity bar), 1 = plain bf16 operands (fast, does NOT meet it; reported only),
- * 8 = split-bf16 with the d_model-input projections of the fused kernels computed from two int8 slices
- * per operand (three int8 MFMAs per product, int32 accumulate; same parity bar). */
-enum { EGOEGO_PREC_BF16X3 = 3, EGOEGO_PREC_BF16X1 = 1, EGOEGO_PREC_I8X3 = 8 };
+ * 8 = the contractions whose input rows have one natural scale — the Q/K/V projections, QK^T, PV and the two FFN convs —
+ * computed from two int8 slices per operand (three int8 MFMAs per product, int32 accumulate; same parity bar); embed, fc and
+ * linear_out stay split-bf16.
+ * 9 = 8 with the attention output projection (fc) on int8 slices as well: the attention kernels hand O over as int8 rows with
+ * one scale per row and head, fc runs one exact integer chain per head.  Same parity bar, about twice the error of 8
+ * (~2.5e-4 against ~1.3e-4 on one forward); faster below ~128 windows per GPU, slightly slower above. */
+enum { EGOEGO_PREC_BF16X3 = 3, EGOEGO_PREC_BF16X1 = 1, EGOEGO_PREC_I8X3 = 8, EGOEGO_PREC_I8X3_FC = 9 };
 
 typedef struct egoego_ctx egoego_ctx;
 
@@ -72,7 +76,7 @@ typedef struct {
     int32_t max_timesteps;  /* window + 1; the position table has max_timesteps + 1 rows (TM:180-182) */
     int32_t num_timesteps;  /* diffusion steps S, 1000 */
     int32_t objective;      /* EGOEGO_PRED_X0 | EGOEGO_PRED_NOISE */
-    int32_t precision;      /* EGOEGO_PREC_BF16X3 | EGOEGO_PREC_BF16X1 | EGOEGO_PREC_I8X3 */
+    int32_t precision;      /* EGOEGO_PREC_BF16X3 | EGOEGO_PREC_BF16X1 | EGOEGO_PREC_I8X3 | EGOEGO_PREC_I8X3_FC */
     int32_t flags;          /* EGOEGO_FLAG_* (0 = defaults) */
 } egoego_config;
 

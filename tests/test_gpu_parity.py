@@ -15,7 +15,7 @@ POSE_TOL = 1e-3      # BASELINE.json north_star: <= 1e-3 max-abs on the final po
 STAGE_TOL = 3e-4     # per-stage intermediates (values up to ~6)
 
 
-@pytest.fixture(params=[_lib.PREC_BF16X3, _lib.PREC_I8X3], ids=["bf16x3", "i8x3"])
+@pytest.fixture(params=[_lib.PREC_BF16X3, _lib.PREC_I8X3, _lib.PREC_I8X3_FC], ids=["bf16x3", "i8x3", "i8x3fc"])
 def prec(request):
     return request.param
 
@@ -38,6 +38,7 @@ def _ref_noise(shape, S, seed=123):
 
 def test_stagewise_against_oracle(prec):
     B, T, H = 2, 120, 4
+    STAGE_TOL = 6e-4 if prec == _lib.PREC_I8X3_FC else globals()["STAGE_TOL"]  # int8 fc: one more 16-bit rounding per layer
     cfg, sd, m = _model(T, precision=prec)
     eng = m.hip_engine()
     x_all = torch.randn(B, T, 396, generator=torch.Generator().manual_seed(1120))

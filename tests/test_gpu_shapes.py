@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 POSE_TOL = 1e-3  # BASELINE.json north_star: <= 1e-3 max-abs on the pose tensor
 
 
-@pytest.fixture(params=[_lib.PREC_BF16X3, _lib.PREC_I8X3], ids=["bf16x3", "i8x3"])
+@pytest.fixture(params=[_lib.PREC_BF16X3, _lib.PREC_I8X3, _lib.PREC_I8X3_FC], ids=["bf16x3", "i8x3", "i8x3fc"])
 def prec(request):
     return request.param
 

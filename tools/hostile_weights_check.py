@@ -31,7 +31,7 @@ def run(gain_mult, n_gain, tail_mult, tail_frac, beta_std):
     x_all = torch.randn(2, 120, 396, generator=g)
     t = torch.tensor([3, 977])
     out = {}
-    for prec in (3, 8):
+    for prec in (3, 8, 9):
         m = CondGaussianDiffusion(**cfg.ctor_kwargs())
         m.load_state_dict(sd, strict=False)
         m.hip_precision = prec
@@ -42,9 +42,9 @@ def run(gain_mult, n_gain, tail_mult, tail_frac, beta_std):
                 ref = m.denoise_fn(x_all.cuda(), t.cuda())  # the module's plain-PyTorch fp32 forward (training path)
         out[prec] = m.denoise(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda())
         layers = getattr(m.hip_engine(), "i8_layers", lambda: None)()
-    e3, e8 = float((out[3] - ref).abs().max()), float((out[8] - ref).abs().max())
+    e3, e8, e9 = (float((out[k] - ref).abs().max()) for k in (3, 8, 9))
     print(f"LN gain x{gain_mult:<4} on {n_gain:2d} features, beta std {beta_std:<4}, QKV weight tails x{tail_mult:<3} ({tail_frac:.3f}): "
-          f"|y|max {float(ref.abs().max()):5.2f}  bf16x3 {e3:.2e}  i8x3 {e8:.2e}" + (f"  i8 layers {layers:04b}" if layers is not None else ""))
+          f"|y|max {float(ref.abs().max()):5.2f}  bf16x3 {e3:.2e}  i8x3 {e8:.2e}  i8x3+fc {e9:.2e}" + (f"  i8 layers {layers:04b}" if layers is not None else ""))
 
 
 for args in ((1, 0, 1, 0, 0), (3, 6, 1, 0, 0), (8, 6, 1, 0, 0), (25, 6, 1, 0, 0), (25, 1, 1, 0, 0), (1, 0, 1, 0, 0.5), (1, 0, 4, 0.002, 0),

@@ -12,7 +12,7 @@ from egoego_release_amd.model import CondGaussianDiffusion
 if "EGOEGO_PERFDEBUG_TAG" in os.environ:  # time an ablation build (build --perfdebug --tag=X -D...)
     _lib.use_perfdebug_build()
 B, T = int(os.environ.get("KT_B", 256)), int(os.environ.get("KT_T", 120))
-prec = int(os.environ.get("KT_PREC", 8))  # 8 = i8x3 (default), 3 = split-bf16 everywhere, 1 = plain bf16
+prec = int(os.environ.get("KT_PREC", 9))  # 9 = i8x3 + int8 fc (default), 8 = i8x3, 3 = split-bf16 everywhere, 1 = plain bf16
 cfg = ModelConfig(max_timesteps=T + 1)
 m = CondGaussianDiffusion(**cfg.ctor_kwargs())
 m.load_state_dict(make_weights(cfg, 0), strict=False)

@@ -18,7 +18,7 @@ g = torch.Generator(device="cpu").manual_seed(3)
 x0 = torch.randn(B, T, 198, generator=g).cuda()
 xc0 = torch.randn(B, T, 198, generator=g).cuda()
 t = torch.randint(0, 1000, (B,), generator=g).cuda()
-for prec in (_lib.PREC_BF16X3, _lib.PREC_I8X3, _lib.PREC_BF16X1):
+for prec in (_lib.PREC_BF16X3, _lib.PREC_I8X3, _lib.PREC_I8X3_FC, _lib.PREC_BF16X1):
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
     m.load_state_dict(make_weights(cfg, 0), strict=False)
     m.hip_precision = prec
@@ -30,6 +30,6 @@ for prec in (_lib.PREC_BF16X3, _lib.PREC_I8X3, _lib.PREC_BF16X1):
     torch.cuda.synchronize()
     out[prec] = (fwd.clone(), x.clone())
 ref = out[_lib.PREC_BF16X3]
-for prec, name in ((_lib.PREC_I8X3, "i8x3"), (_lib.PREC_BF16X1, "bf16x1")):
+for prec, name in ((_lib.PREC_I8X3, "i8x3"), (_lib.PREC_I8X3_FC, "i8x3+fc"), (_lib.PREC_BF16X1, "bf16x1")):
     print(f"{name:7s} vs bf16x3: forward {float((out[prec][0] - ref[0]).abs().max()):.3e}   "
           f"{steps}-step chain {float((out[prec][1] - ref[1]).abs().max()):.3e}   (|x| max {float(ref[1].abs().max()):.2f})")

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--batches", default="1,16,32,64,128,256")
     ap.add_argument("--windows", default="120")
-    ap.add_argument("--precision", type=int, default=8)
+    ap.add_argument("--precision", type=int, default=9)
     ap.add_argument("--api", action="store_true", help="also time model.sample() with sampling_rng torch / philox")
     a = ap.parse_args()
     for T in [int(v) for v in a.windows.split(",")]:
