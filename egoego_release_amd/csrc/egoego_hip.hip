@@ -429,7 +429,9 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
     return 0;
 }
 static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
-    if (ta.fc8) {  // int8 fc: 32-token workgroups only (64-token ones need more than 512 registers per lane)
+    if (ta.fc8) {
+        // int8 fc: 32-token workgroups at every batch size.  (64-token ones — tail_kernel<2, true, true>, fc in two feature
+        // passes — measured slower: 250 against 235 us per launch at B=256, 0.94 against 0.80 ms per step at B=128.)
         static bool once = false;
         if (!once) {
             HIP_TRY(allow_smem((tail_kernel<1, true, true>), tail_smem_bytes(1)));

@@ -312,28 +312,36 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
 
     // =============================================================== 1. fc + residual + LayerNorm (TM:92-93, 135)
     if constexpr (FC8) {
-        using GF = DirectGemm<FT, TT, (TT == 2 ? 2 : 4), false, true>;
-        I8Acc q[FT][TT];
-        float so[TT];
+        // One exact integer chain per head (8 k-blocks = one chunk), folded into the fp32 running sum `acc` between chains.
+        // A wave's 4 feature tiles go in FP passes of 4 / FP tiles: with 64 tokens per workgroup (TT = 2) the I8Acc pairs of
+        // all 8 tiles next to their 8 running-sum tiles would exceed the register file, so the two feature halves run one
+        // after the other (the activation chunks are streamed twice, the weights once either way).
+        constexpr int FP = TT, FTP = FT / FP;
+        using GF = DirectGemm<FTP, TT, 4, false, true>;
+        const int col = lane & 31;
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int col = lane & 31;
-        GF::run(q, (const __bf16*)a.o8, a.o8_plane / 2, a.HD16 / 2, (const __bf16*)a.wfc8, a.wfc8_plane / 2, act, tt0, wave, lane, [&] { mark(7); }, -1,
-                [&](int h) {  // head h's chain is complete: fold it into the running sum and start the next one from zero
 #pragma unroll
-                    for (int j = 0; j < TT; ++j) so[j] = a.o_scale[(size_t)(tok0 + j * 32 + col) * a.H + h] * 256.0f;
+        for (int fp = 0; fp < FP; ++fp) {
+            I8Acc q[FTP][TT];
+            GF::run(q, (const __bf16*)a.o8, a.o8_plane / 2, a.HD16 / 2, (const __bf16*)a.wfc8, a.wfc8_plane / 2, act, tt0, wave, lane, [&] { mark(7); },
+                    wave * FT + fp * FTP, [&](int h) {  // head h's chain is complete: fold it into the running sum, start the next from zero
+                        float so[TT];
 #pragma unroll
-                    for (int i = 0; i < FT; ++i)
+                        for (int j = 0; j < TT; ++j) so[j] = a.o_scale[(size_t)(tok0 + j * 32 + col) * a.H + h] * 256.0f;
 #pragma unroll
-                        for (int j = 0; j < TT; ++j) {
-                            i8_fold(q[i][j], acc[i][j], so[j]);
-                            acc_zero(q[i][j]);
-                        }
-                });
+                        for (int i = 0; i < FTP; ++i)
+#pragma unroll
+                            for (int j = 0; j < TT; ++j) {
+                                i8_fold(q[i][j], acc[fp * FTP + i][j], so[j]);
+                                acc_zero(q[i][j]);
+                            }
+                    });
+        }
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
