@@ -431,13 +431,20 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
 static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
     if (ta.fc8) {
         // int8 fc: 32-token workgroups at every batch size.  (64-token ones — tail_kernel<2, true, true>, fc in two feature
-        // passes — measured slower: 250 against 235 us per launch at B=256, 0.94 against 0.80 ms per step at B=128.)
+        // passes, one workgroup per CU — measured slower: 250 against 235 us per launch at B=256, 0.94 against 0.80 ms per step at
+        // B=128: what a large grid needs is more bytes in flight per CU, not fewer bytes per token.)
         static bool once = false;
         if (!once) {
             HIP_TRY(allow_smem((tail_kernel<1, true, true>), tail_smem_bytes(1)));
+            HIP_TRY(allow_smem((tail_kernel<1, true, true, true>), tail_smem_bytes(1)));
             once = true;
         }
-        tail_kernel<1, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+        // more than one workgroup per CU: the 256-register build, two workgroups per CU (measured at B=256: 190 against 235 us per
+        // launch; at B=32 / 64, one workgroup per CU either way, the two builds take the same time)
+        if (rows / 32 > 256)
+            tail_kernel<1, true, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+        else
+            tail_kernel<1, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -284,8 +284,13 @@ struct DirectGemm {
 // late: a LayerNorm epilogue that takes 13 us alone takes 60 us next to a wave that saturates the matrix pipe of the same SIMD.)
 // FFN8: the two FFN contractions on int8 slices (TailArgs::ffn8 ...; the i8x3 precision); FC8: fc too (TailArgs::fc8 ...) —
 // separate instantiations, so that the split-bf16 kernel's register allocation is untouched.
-template <int TT, bool FFN8, bool FC8 = false>
-__global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
+// W2 (int8 fc + FFN only): a 256-register build, TWO workgroups per CU — for grids of more than one workgroup per CU, where a
+// lone workgroup's weight stream is latency-bound (bytes in flight / L2 latency): a second resident workgroup doubles the bytes
+// in flight and fills the other's epilogues.  Every contraction then runs its 4 feature tiles per wave in two passes of 2
+// (I8Acc pairs of 2 tiles + a 4-slot weight ring = 128 registers); integer sums and float operations are unchanged: same bits.
+template <int TT, bool FFN8, bool FC8 = false, bool W2 = false>
+__global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
+    static_assert(!W2 || (FFN8 && FC8 && TT == 1), "the two-workgroups-per-CU build exists for the all-int8 32-token tail");
     constexpr int TOK = 32 * TT, FT = 4;
     using G = DirectGemm<FT, TT, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
         // A wave's 4 feature tiles go in FP passes of 4 / FP tiles: with 64 tokens per workgroup (TT = 2) the I8Acc pairs of
         // all 8 tiles next to their 8 running-sum tiles would exceed the register file, so the two feature halves run one
         // after the other (the activation chunks are streamed twice, the weights once either way).
-        constexpr int FP = TT, FTP = FT / FP;
+        constexpr int FP = W2 ? 2 : TT, FTP = FT / FP;
         using GF = DirectGemm<FTP, TT, 4, false, true>;
         const int col = lane & 31;
 #pragma unroll
@@ -361,11 +366,18 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
     if constexpr (FFN8) {
         // int8 slices, one pass into I8Acc pairs (a lone wave per SIMD has the registers): the integer sums — and so every
         // bit downstream — equal the two-pass one-accumulator form of the large-batch kernel (layer_tail_i8_kernel)
-        using G8 = DirectGemm<FT, TT, (TT == 2 ? 2 : 4), false, true>;  // TT = 2: 256 accumulator registers, so a 2-slot weight ring
+        constexpr int FP8 = W2 ? 2 : 1, FTP8 = FT / FP8;  // feature passes of the FFN contractions (W2: two of 2 tiles)
+        using G8 = DirectGemm<FTP8, TT, (TT == 2 ? 2 : 4), false, true>;  // TT = 2: 256 accumulator registers, so a 2-slot weight ring
         const EpiReluQ8<4, TOK> e8{a.relu8.bias, a.relu8.q8, a.relu8.q8_plane, a.relu8.q8_scale};
+        auto ffn_gemm = [&](I8Acc (&q)[FT][TT], const int8_t* in8, size_t in_plane_bytes, const int8_t* w8, int mk) {
+#pragma unroll
+            for (int fp = 0; fp < FP8; ++fp)
+                G8::run(*(I8Acc(*)[FTP8][TT]) & q[fp * FTP8], (const __bf16*)in8, in_plane_bytes / 2, 16, (const __bf16*)w8, a.w8_plane / 2, act, tt0, wave,
+                        lane, [&] { mark(mk); }, wave * FT + fp * FTP8);
+        };
         {
             I8Acc q[FT][TT];
-            G8::run(q, (const __bf16*)a.ln1.q8, a.ln1.q8_plane / 2, 16, (const __bf16*)a.w1_8, a.w8_plane / 2, act, tt0, wave, lane, [&] { mark(8); });
+            ffn_gemm(q, a.ln1.q8, a.ln1.q8_plane, a.w1_8, 8);
             mark(3);
             e8.template run<false, I8Acc, FT, TT>(q, a.s_w1, a.ln1.q8_scale, wave * FT * 32, tok0, lane, wave, 0, red);
         }
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(TailArgs a) {
         // =========================================================== 3. FFN w_2 + residual + LayerNorm (TM:111-114, 139)
         {
             I8Acc q[FT][TT];
-            G8::run(q, (const __bf16*)a.relu8.q8, a.relu8.q8_plane / 2, 16, (const __bf16*)a.w2_8, a.w8_plane / 2, act, tt0, wave, lane, [&] { mark(9); });
+            ffn_gemm(q, a.relu8.q8, a.relu8.q8_plane, a.w2_8, 9);
             mark(5);
             i8_dequant_tile<false>(q, acc, a.s_w2, a.relu8.q8_scale, wave * FT * 32, tok0, lane);
         }
