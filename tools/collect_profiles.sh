@@ -13,5 +13,5 @@ cp $(find $O/stats_b32 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_
 cp $(find $O/stats_t196 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_b256_t196_kernel_stats.csv
 A=$(find $O/pmc_a -name "*counter_collection.csv" | head -1); B=$(find $O/pmc_b -name "*counter_collection.csv" | head -1); C=$(find $O/pmc_c -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $A $B $C > profiles/${R}_pmc_per_kernel.csv
-EGOEGO_ROUND=$R python3 tools/traffic_json.py $A $B 256 120 8
+EGOEGO_ROUND=$R python3 tools/traffic_json.py $A $B 256 120 9
 EGOEGO_ROUND=$R python3 tools/roofline_report.py
