@@ -28,6 +28,7 @@ struct Qkv8Out {
     const float* bias;     // [3*HD]
     float qscale;          // 1 / sqrt(d_k)
     int Lp, KT, H, HD, Mvalid;
+    int Lr;                // token rows per window in the ROW space (a multiple of 16, <= Lp = 32 KT): window b owns rows b Lr .. b Lr + Lr - 1
 };
 
 // Quantise 16 values, each with its own inverse scale, into the two slices (cf. common.h quant16).
@@ -92,13 +93,15 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
         float* dsts = which == 0 ? o.sq : o.sk;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m0 = t0 + j * 32;
-            if (m0 >= o.Mvalid) continue;
-            const int b = m0 / o.Lp, lt = (m0 % o.Lp) >> 5, bh = b * o.H + h;
+            // the lane's token: row m of the row space = token l of window b (windows start on 16-row boundaries, so a
+            // 32-row tile may hold the end of one window and the start of the next: the destination is per lane)
+            const int m = t0 + j * 32 + col;
+            if (m >= o.Mvalid) continue;
+            const int b = m / o.Lr, l = m - b * o.Lr, bh = b * o.H + h;
             const int tokb = j * 32 + col;
             const float rmax = fmaxf(fmaxf(red[tokb], red[64 + tokb]), fmaxf(red[128 + tokb], red[192 + tokb]));
             const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
-            if (wf == 0 && hf == 0) dsts[(size_t)bh * o.Lp + lt * 32 + col] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+            if (wf == 0 && hf == 0) dsts[(size_t)bh * o.Lp + l] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float t[16];
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
                 for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
                 u32x4 s1, s2;
                 quant16(t, inv, s1, s2);
-                int8_t* p = dst8 + ((((size_t)bh * o.KT + lt) * 8 + wf * 2 + i) << 10) + lane * 16;
+                int8_t* p = dst8 + ((((size_t)bh * o.KT + (l >> 5)) * 8 + wf * 2 + i) << 10) + (hf * 32 + (l & 31)) * 16;
                 *(u32x4*)p = s1;
                 *(u32x4*)(p + o.plane) = s2;
             }
@@ -147,27 +150,40 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m0 = t0 + j * 32;
-            if (m0 >= o.Mvalid) continue;
-            const int b = m0 / o.Lp, lt = (m0 % o.Lp) >> 5, bh = b * o.H + h;
-            float inv[16];
+            float inv[16], rm[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tokb = j * 32 + mfma32_row(r, hf);
-                const float rmax = fmaxf(fmaxf(red[tokb], red[64 + tokb]), fmaxf(red[128 + tokb], red[192 + tokb]));
-                inv[r] = rmax > 0.f ? I8_QMAX / rmax : 0.f;
-                if (wf == 0 && col == 0) o.sv[(size_t)bh * o.Lp + lt * 32 + mfma32_row(r, hf)] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+                rm[r] = fmaxf(fmaxf(red[tokb], red[64 + tokb]), fmaxf(red[128 + tokb], red[192 + tokb]));
+                inv[r] = rm[r] > 0.f ? I8_QMAX / rm[r] : 0.f;
             }
+            float t[2][16];
+            u32x4 s1[2], s2[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float t[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
-                u32x4 s1, s2;
-                quant16v(t, inv, s1, s2);
-                int8_t* p = o.v8 + ((((size_t)bh * 8 + wf * 2 + i) * o.KT + lt) << 10) + lane * 16;
-                *(u32x4*)p = s1;
-                *(u32x4*)(p + o.plane) = s2;
+                for (int r = 0; r < 16; ++r) t[i][r] = v[i][j][r];
+                quant16v(t[i], inv, s1[i], s2[i]);
+            }
+            // A lane's 16 bytes of a tile are two runs of 8 keys: registers 0..7 = the tile's rows 0..15, 8..15 = rows 16..31.
+            // Windows start on 16-row boundaries, so each run lies in ONE window: it goes, as 8 bytes, to the half of that
+            // window's key tile it belongs to (acc32 order: keys 0..15 of a 32-key tile are bytes 0..7, keys 16..31 bytes 8..15).
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int m0 = t0 + j * 32 + 16 * g2;
+                if (m0 >= o.Mvalid) continue;
+                const int b = m0 / o.Lr, l0 = m0 - b * o.Lr, bh = b * o.H + h;
+                if (wf == 0 && col == 0) {
+#pragma unroll
+                    for (int r = 8 * g2; r < 8 * g2 + 8; ++r)
+                        o.sv[(size_t)bh * o.Lp + l0 + (mfma32_row(r, hf) & 15)] = rm[r] > 0.f ? rm[r] / I8_QMAX : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int8_t* p = o.v8 + ((((size_t)bh * 8 + wf * 2 + i) * o.KT + (l0 >> 5)) << 10) + lane * 16 + ((l0 >> 4) & 1) * 8;
+                    *(uint2*)p = make_uint2(s1[i][2 * g2], s1[i][2 * g2 + 1]);
+                    *(uint2*)(p + o.plane) = make_uint2(s2[i][2 * g2], s2[i][2 * g2 + 1]);
+                }
             }
         }
     }
@@ -180,6 +196,7 @@ struct AttnCore8Args {
     __bf16* o;  // [Mp][HD] split-bf16 fragment-tiled (accumulator order): the fc GEMM's operand
     size_t o_plane;
     int HD16, H, L, Lp;
+    int Lr;     // token rows per window in the row space (<= Lp); query l of window b is row b Lr + l
     // o8 != nullptr: O as int8 slices with one scale per row and head (see AttnLayerArgs)
     int8_t* o8;
     size_t o8_plane;
@@ -202,8 +219,9 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
     const int qt_raw = qb * 4 + wave;
-    const bool active = qt_raw < KT;
-    const int qt = active ? qt_raw : KT - 1;
+    const bool tile_active = qt_raw < KT;
+    const int qt = tile_active ? qt_raw : KT - 1;
+    const bool active = tile_active && qt * 32 + col < a.Lr;  // per lane: the last query tile may reach beyond the window's rows
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)a.k8, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)a.v8, 0, 0x7fffffff, 0x00020000);
     constexpr int NPIECE = KT * 8 / 4;  // 1-KiB pieces of a half image (both slices) per wave: KT*4 blocks x 2 slices / 4 waves
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     }
 
     // ---- O^T = V^T P (TM:83-88) per d_v half, heads merged on store
-    const int m = b * a.Lp + qt * 32 + col;
+    const int m = b * a.Lr + qt * 32 + col;
     float t8[8][16];  // int8 output: the first half's values wait for the row maximum over the head's 256 features
     float amax = 0.f;
 #pragma unroll

@@ -98,19 +98,23 @@ struct egoego_ctx {
 };
 
 static const int N_MODEL = 512;
-// the int8-slice precisions: EGOEGO_PREC_I8X3 (attention layer + FFN) and EGOEGO_PREC_I8X3_FC (the same + fc)
-static inline bool prec_i8(const egoego_ctx* c) { return c->cfg.precision == EGOEGO_PREC_I8X3 || c->cfg.precision == EGOEGO_PREC_I8X3_FC; }
 #ifdef EGOEGO_PERFDEBUG
 // perf-debug build only (tools/*_trace.py): per-block timestamps and stage ablation, set through egoego_debug_*
 static unsigned long long* g_trace = nullptr;
 static int g_ablate = 0;
 #endif
 
+// the int8-slice precisions: EGOEGO_PREC_I8X3 (attention layer + FFN) and EGOEGO_PREC_I8X3_FC (the same + fc)
+static inline bool prec_i8(const egoego_ctx* c) { return c->cfg.precision == EGOEGO_PREC_I8X3 || c->cfg.precision == EGOEGO_PREC_I8X3_FC; }
+
 struct Geometry {
-    int B, T, L, KT, Lp, Mp, Mvalid;
+    int B, T, L, KT, Lp, Lr, Mp, Mvalid;  // Lp = 32 KT: tokens of a window's attention images; Lr: token ROWS per window (row stride)
 };
 
-static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g) {
+// aligned: every window on 32-row tile boundaries (Lr = Lp) — what the split-bf16 attention kernels and the Q/K/V debug stops need.
+// Otherwise long windows of the int8 precisions are packed on 16-row boundaries: 208 rows instead of 224 for 129..208 tokens
+// (BASELINE configs[3]: T + 1 = 197), 7 % fewer rows through every row-parallel kernel; only the attention images keep 32-key tiles.
+static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g, bool aligned = false) {
     if (B < 1 || T < 1) return fail(EGOEGO_E_INVALID, "B and T must be positive (B=%d, T=%d)", B, T);
     if (T > c->cfg.max_timesteps - 1)
         return fail(EGOEGO_E_INVALID, "window length T=%d exceeds max_timesteps-1=%d (position table rows, TM:180-182)", T,
@@ -122,10 +126,11 @@ static int make_geometry(const egoego_ctx* c, int B, int T, Geometry& g) {
     else if (g.L <= 224) g.KT = 7;
     else return fail(EGOEGO_E_INVALID, "window length T=%d not supported (T+1 must be <= 224)", T);
     g.Lp = 32 * g.KT;
+    g.Lr = (!aligned && prec_i8(c) && g.KT == 7 && g.L <= 208) ? 208 : g.Lp;
     // 32-bit byte offsets into one operand plane (buffer-resource addressing, rows x 2 KiB at most): 2^20 padded rows per call
     if ((size_t)B * g.Lp > (size_t)1 << 20)
         return fail(EGOEGO_E_INVALID, "B=%d windows of %d padded rows exceed 1048576 rows per call: split the batch", B, g.Lp);
-    g.Mvalid = B * g.Lp;
+    g.Mvalid = B * g.Lr;
     g.Mp = (int)align_up((size_t)g.Mvalid, 256);
     return 0;
 }
@@ -521,8 +526,8 @@ template <int NP>
 static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, const StepIO& io, hipStream_t s, int w0,
                         int nw) {
     const int H = c->H, HD = c->HD;
-    const int row0 = w0 * g.Lp;
-    int rows = nw * g.Lp;
+    const int row0 = w0 * g.Lr;
+    int rows = nw * g.Lr;
     if (w0 + nw >= g.B) rows = g.Mp - row0;  // the last chunk also carries the rows that pad Mp to the block size
     const int tb_a = rows / BLK_A_T, tb_b = rows / BLK_B_T, tb_c = rows / CfgC<NP>::BT;
     const int t0_a = row0 / BLK_A_T, t0_b = row0 / BLK_B_T, t0_c = row0 / CfgC<NP>::BT;
@@ -540,17 +545,17 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         if (NP == 2 && direct_embed) {
             // small grids: weights streamed into registers, activations by LDS-DMA chunks (tail_fused.h), same arithmetic
             EmbedArgs ea{w.xall, w.xall_plane, c->KE / 16, c->w_embed, (size_t)N_MODEL * c->KE,
-                         EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, i8_path ? w.hA8 : nullptr,
+                         EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lr, g.T, g.B, i8_path ? w.hA8 : nullptr,
                                            w.h_plane, i8_path ? w.hA_scale : nullptr, io.state, io.ts}};
             if (int r = launch_embed_tt<1>(ea, rows, s)) return r;
         } else if (i8_path) {
             // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
-            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
+            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lr, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
             if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
         } else {
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
-            EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lp, g.T, g.B, nullptr, 0, nullptr, io.state, io.ts};
+            EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lr, g.T, g.B, nullptr, 0, nullptr, io.state, io.ts};
             if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
         }
     }
@@ -559,6 +564,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         const LayerDev& L = c->layers[li];
         const bool last_dbg = (li == io.stop_layer);
         const bool dbg_qkv = last_dbg && (io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V);
+        // (the split-bf16 projection epilogues place whole 32-row tiles: they only ever run on aligned geometries, Lr == Lp)
         EpiQK<NP> eqk{L.b_qkv, w.Q, w.K, w.qkv_plane, 1.0f / sqrtf((float)c->cfg.d_k), g.Lp, H, HD, g.Mvalid};
         EpiV<NP> ev{L.b_qkv, w.V, w.qkv_plane, g.Lp, H, HD, g.Mvalid};
         AttnArgs aa{w.Q, w.K, w.V, w.qkv_plane, w.O, w.o_plane, HD / 16, H, g.L, w0 * H};
@@ -611,7 +617,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     ProfScope ps(c, EGOEGO_K_QKV, s);
                     QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, rows / 64, 2 * HD / BLK_A_F};
                     Qkv8Out qo{(int8_t*)w.Q, (int8_t*)w.K, (int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, L.b_qkv,
-                               1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid};
+                               1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid, g.Lr};
                     static bool once = false;
                     if (!once) {
                         HIP_TRY(allow_smem(qkv_i8q_kernel, Q8K::SMEM_BYTES));
@@ -623,7 +629,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 {
                     ProfScope ps(c, EGOEGO_K_ATTN, s);
                     AttnCore8Args ca{(const int8_t*)w.Q, (const int8_t*)w.K, (const int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, w.O, w.o_plane,
-                                     HD / 16, H, g.L, g.Lp};
+                                     HD / 16, H, g.L, g.Lp, g.Lr};
                     if (fc8) {
                         ca.o8 = w.O8; ca.o8_plane = w.o_plane; ca.o_scale = w.O_scale;
                     }
@@ -824,8 +830,8 @@ static int check_ready(const egoego_ctx* c, bool need_sched) {
     return 0;
 }
 
-static int prepare(egoego_ctx* c, int B, int T, void* d_ws, size_t ws_bytes, Geometry& g, Workspace& w) {
-    if (int r = make_geometry(c, B, T, g)) return r;
+static int prepare(egoego_ctx* c, int B, int T, void* d_ws, size_t ws_bytes, Geometry& g, Workspace& w, bool aligned = false) {
+    if (int r = make_geometry(c, B, T, g, aligned)) return r;
     if (!d_ws || ((uintptr_t)d_ws & 255)) return fail(EGOEGO_E_WORKSPACE, "workspace must be a 256-byte aligned device pointer");
     carve(c, g, (char*)d_ws, w);
     if (ws_bytes < w.total)
@@ -837,11 +843,13 @@ static int pack_inputs(egoego_ctx* c, const Geometry& g, const Workspace& w, con
                        const float* d_row_mask, const float** packed_mask, hipStream_t s) {
     const size_t n = (size_t)g.Mp * (c->KE / 2);
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    k_pack_pose<<<blocks, 256, 0, s>>>(d_x, d_xc, w.xall, w.xall_plane, g.Mp, c->KE, g.Lp, g.T, g.B, c->D, c->DP, 1);
+    k_pack_pose<<<blocks, 256, 0, s>>>(d_x, d_xc, w.xall, w.xall_plane, g.Mp, c->KE, g.Lr, g.T, g.B, c->D, c->DP, 1);
+    if (g.Lr != g.Lp)  // keys Lr .. Lp-1 of every window exist in the attention images only: their V scales must be finite (they meet probability 0)
+        HIP_TRY(hipMemsetAsync(w.sv8, 0, sizeof(float) * (size_t)g.B * c->H * g.Lp, s));
     HIP_TRY(hipGetLastError());
     *packed_mask = nullptr;
     if (d_row_mask) {
-        k_pack_row_mask<<<(g.Mp + 255) / 256, 256, 0, s>>>(d_row_mask, w.row_mask, g.Mp, g.Lp, g.T, g.B);
+        k_pack_row_mask<<<(g.Mp + 255) / 256, 256, 0, s>>>(d_row_mask, w.row_mask, g.Mp, g.Lr, g.T, g.B);
         HIP_TRY(hipGetLastError());
         *packed_mask = w.row_mask;
     }
@@ -858,7 +866,7 @@ static void base_out_params(const egoego_ctx* c, const Geometry& g, const Worksp
     o.t_idx = w.t_idx;
     o.objective = c->cfg.objective;
     o.clip = 1;
-    o.Lp = g.Lp; o.T = g.T; o.B = g.B; o.D = c->D; o.DP = c->DP;
+    o.Lp = g.Lr; o.T = g.T; o.B = g.B; o.D = c->D; o.DP = c->DP;
 }
 
 // ==================================================================================== C ABI
@@ -1076,7 +1084,7 @@ int egoego_load_schedule(egoego_ctx* c, const egoego_schedule* sc, void* stream)
 
 size_t egoego_workspace_bytes(const egoego_ctx* c, int B, int T) {
     Geometry g;
-    if (!c || make_geometry(c, B, T, g)) return 0;
+    if (!c || make_geometry(c, B, T, g, true)) return 0;  // the aligned geometry is the larger one: it covers both
     Workspace w;
     carve(c, g, nullptr, w);
     return w.total;
@@ -1394,7 +1402,7 @@ int egoego_debug_stage(egoego_ctx* c, const float* d_x, const float* d_xc, const
     HIP_TRY(hipSetDevice(c->device));
     Geometry g;
     Workspace w;
-    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w, true)) return r;  // the Q/K/V stops run the tile-aligned split-bf16 projections
     StepIO io{};
     if (int r = pack_inputs(c, g, w, d_x, d_xc, d_row_mask, &io.row_mask, s)) return r;
     k_convert_t<<<(B + 255) / 256, 256, 0, s>>>(d_t, w.t_idx, B, c->S);

@@ -240,10 +240,12 @@ def test_ddim_against_oracle_restatement(prec):
 
 
 @pytest.mark.parametrize("B,T,n_head,n_layers", [(1, 1, 4, 4), (3, 2, 4, 4), (5, 31, 4, 4), (3, 63, 4, 4), (2, 95, 4, 4), (3, 96, 4, 4), (2, 127, 4, 4),
-                                                  (2, 128, 4, 4), (1, 223, 4, 4), (2, 50, 2, 1), (2, 120, 8, 2)])
+                                                  (2, 128, 4, 4), (3, 191, 4, 4), (2, 207, 4, 4), (2, 208, 4, 4), (1, 223, 4, 4), (2, 50, 2, 1), (2, 120, 8, 2)])
 def test_shape_edge_cases_against_oracle(B, T, n_head, n_layers, prec):
     """Minimum window (T=1), every key-tile boundary (L = 32/64/65/96/97/128/129; 65..128 is the one-kernel i8x3 attention layer's range), the maximum supported window
-    (T=223), odd batches, and other head / layer counts than the shipped checkpoint's."""
+    (T=223), the 16-row packing of long windows in the int8 precisions (L = 129 / 192 / 208 pack at 208 rows per window, so odd
+    windows start in the middle of a 32-row tile; L = 209 falls back to 224), odd batches, and other head / layer counts than the
+    shipped checkpoint's."""
     cfg = ModelConfig(max_timesteps=T + 1, n_head=n_head, n_dec_layers=n_layers)
     sd = make_weights(cfg, 3)
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
