@@ -28,6 +28,15 @@
 #ifndef TAIL_ABLATE
 #define TAIL_ABLATE 0
 #endif
+// weight-ring depth (k-steps of register prefetch + 1) of the one-workgroup-per-CU builds: the all-int8 tail / embed and linear_out.
+// Measured at B=32 / 64 (round 3): depth 8 (with the FFNs in two feature passes to make room) is 4 % SLOWER for the tail (0.407 vs
+// 0.391 ms per step at B=32) and changes nothing for embed / linear_out — a lone workgroup per CU is not short of bytes in flight.
+#ifndef TAIL_RING1
+#define TAIL_RING1 4
+#endif
+#ifndef TAIL_RING_IO
+#define TAIL_RING_IO 4
+#endif
 
 struct TailArgs {
     // fc + residual + LayerNorm (TM:92-93, 135)
@@ -321,8 +330,8 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
         // A wave's 4 feature tiles go in FP passes of 4 / FP tiles: with 64 tokens per workgroup (TT = 2) the I8Acc pairs of
         // all 8 tiles next to their 8 running-sum tiles would exceed the register file, so the two feature halves run one
         // after the other (the activation chunks are streamed twice, the weights once either way).
-        constexpr int FP = W2 ? 2 : TT, FTP = FT / FP;
-        using GF = DirectGemm<FTP, TT, 4, false, true>;
+        constexpr int FP = (W2 || TAIL_RING1 == 8) ? 2 : TT, FTP = FT / FP;
+        using GF = DirectGemm<FTP, TT, (W2 ? 4 : TAIL_RING1), false, true>;
         const int col = lane & 31;
 #pragma unroll
         for (int i = 0; i < FT; ++i)
@@ -366,8 +375,8 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
     if constexpr (FFN8) {
         // int8 slices, one pass into I8Acc pairs (a lone wave per SIMD has the registers): the integer sums — and so every
         // bit downstream — equal the two-pass one-accumulator form of the large-batch kernel (layer_tail_i8_kernel)
-        constexpr int FP8 = W2 ? 2 : 1, FTP8 = FT / FP8;  // feature passes of the FFN contractions (W2: two of 2 tiles)
-        using G8 = DirectGemm<FTP8, TT, (TT == 2 ? 2 : 4), false, true>;  // TT = 2: 256 accumulator registers, so a 2-slot weight ring
+        constexpr int FP8 = (W2 || (TT == 1 && TAIL_RING1 == 8)) ? 2 : 1, FTP8 = FT / FP8;  // feature passes of the FFN contractions (two of 2 tiles where the ring is deep or the registers few)
+        using G8 = DirectGemm<FTP8, TT, (TT == 2 ? 2 : (W2 ? 4 : TAIL_RING1)), false, true>;  // TT = 2: 256 accumulator registers, so a 2-slot weight ring
         const EpiReluQ8<4, TOK> e8{a.relu8.bias, a.relu8.q8, a.relu8.q8_plane, a.relu8.q8_scale};
         auto ffn_gemm = [&](I8Acc (&q)[FT][TT], const int8_t* in8, size_t in_plane_bytes, const int8_t* w8, int mk) {
 #pragma unroll
@@ -430,7 +439,7 @@ struct EmbedArgs {
 };
 template <int TT>
 __global__ __launch_bounds__(256, 1) void embed_kernel(EmbedArgs a) {
-    using G = DirectGemm<4, TT, 4, true>;  // the embed operand has 26 k-blocks (2 x 208 columns)
+    using G = DirectGemm<4, TT, TAIL_RING_IO, true>;  // the embed operand has 26 k-blocks (2 x 208 columns)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
     f32x16 acc[4][TT];
@@ -452,7 +461,7 @@ struct OutArgs {
 template <int TT, int FS>
 __global__ __launch_bounds__(256, 1) void out_kernel(OutArgs a) {
     constexpr int FT = 2 / FS;
-    using G = DirectGemm<FT, TT, 4>;
+    using G = DirectGemm<FT, TT, TAIL_RING_IO>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
     const int tb = (int)blockIdx.x / FS, fh = (int)blockIdx.x % FS;
