@@ -540,18 +540,22 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     // i8x3: windows of 65..128 tokens go through the int8-slice attention-layer kernel at any batch size, and its first
     // layer reads the embed output as int8 rows
     const bool i8_path = NP == 2 && prec_i8(c);  // every layer input also as int8 rows
+    // precision 9, windows of more than 64 tokens: a layer's inter-kernel activations exist as int8 rows ONLY (residuals are
+    // rebuilt from them); the split-bf16 copies are written just for the debug stops and, after the last layer, for linear_out
+    const bool act8_only = i8_path && c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7) && io.stop_stage < 0;
+    __bf16* const embed_out = act8_only ? nullptr : w.hA;
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
         if (NP == 2 && direct_embed) {
             // small grids: weights streamed into registers, activations by LDS-DMA chunks (tail_fused.h), same arithmetic
             EmbedArgs ea{w.xall, w.xall_plane, c->KE / 16, c->w_embed, (size_t)N_MODEL * c->KE,
-                         EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lr, g.T, g.B, i8_path ? w.hA8 : nullptr,
+                         EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, embed_out, w.h_plane, g.Lr, g.T, g.B, i8_path ? w.hA8 : nullptr,
                                            w.h_plane, i8_path ? w.hA_scale : nullptr, io.state, io.ts}};
             if (int r = launch_embed_tt<1>(ea, rows, s)) return r;
         } else if (i8_path) {
             // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
-            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lr, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
+            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, embed_out, w.h_plane, g.Lr, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
             if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
         } else {
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
@@ -693,6 +697,12 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 ta.relu = EpiTiled<true, 2>{L.b_1, w.F, w.h_plane, N_MODEL / 16};
                 ta.w2 = L.w_2; ta.w2_plane = (size_t)N_MODEL * N_MODEL;
                 ta.ln2 = EpiResLN<2, 4, 0>{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                if (act8_only) {
+                    // residuals from the int8 rows; split-bf16 rows only out of the last layer (linear_out's operand)
+                    ta.ln1.res8 = w.hA8; ta.ln1.res8_plane = w.h_plane; ta.ln1.res8_scale = w.hA_scale; ta.ln1.out = nullptr;
+                    ta.ln2.res8 = w.hB8; ta.ln2.res8_plane = w.h_plane; ta.ln2.res8_scale = w.hB_scale;
+                    if (li + 1 < c->cfg.n_dec_layers) ta.ln2.out = nullptr;
+                }
                 ta.stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
                 EG_DBG(ta.trace = g_trace;)
                 if (int r = launch_tail(ta, rows, s)) return r;

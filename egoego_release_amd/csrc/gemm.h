@@ -735,6 +735,11 @@ struct EpiResLN {
     int8_t* q8;       // optional: the same rows as int8 slices (fragment-tiled, accumulator order) for an i8x3 consumer
     size_t q8_plane;  // bytes between the two slices
     float* q8_scale;  // [Mp] row scales
+    // optional: the residual as int8 rows (the same layout: a lane's 16 accumulator values of a tile are 16 consecutive bytes per
+    // slice) instead of `res` — precision 9 keeps every inter-kernel activation of a layer as int8 rows only; `out` may then be null
+    const int8_t* res8;
+    size_t res8_plane;
+    const float* res8_scale;
     template <int FT, int TT>
     __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem) const {
         static_assert(NWF * FT * 32 == 512, "LayerNorm epilogue needs the whole 512-wide row in the block");
@@ -753,6 +758,25 @@ struct EpiResLN {
             const int m = t0 + j * 32 + col;
             slot[j] = (j * NWF) * BT + (wt * TT + j) * 32 + col;
             float s1 = 0.f;
+            if (res8) {
+                const float rs = res8_scale[m];
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    const size_t idx8 = acc_slot_i8(m, f0 + i * 32, hf, 16);
+                    float r[16];
+                    dequant16(*(const u32x4*)(res8 + idx8), *(const u32x4*)(res8 + res8_plane + idx8), rs, r);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *(const float4*)(bias + f0 + i * 32 + 8 * g + 4 * hf);
+                        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            acc[i][j][4 * g + c] += bb[c] + r[4 * g + c];
+                            s1 += acc[i][j][4 * g + c];
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -931,11 +955,13 @@ struct EpiEmbed {
                             amax = fmaxf(amax, fabsf(v[c]));
                         }
                     }
-                    u32x4 hi, lo;
-                    split8(v, hi, lo);
-                    const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
-                    *(u32x4*)(out + idx) = hi;
-                    if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
+                    if (out) {  // (null in precision 9 outside debug runs: layer 0 reads the int8 rows only)
+                        u32x4 hi, lo;
+                        split8(v, hi, lo);
+                        const size_t idx = acc_slot(m, f0 + i * 32, jj, hf, 32);
+                        *(u32x4*)(out + idx) = hi;
+                        if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
+                    }
                 }
             if (Q8 && q8) {
                 amax = fmaxf(amax, __shfl_xor(amax, 32));

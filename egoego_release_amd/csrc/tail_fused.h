@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
     f32x16 acc[FT][TT];
     // epilogue structs carry the large-batch kernels' code; only the tokens-per-block template argument differs
     auto as_ln = [&](const EpiResLN<2, 4, 0>& e) {
-        return EpiResLN<2, 4, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale};
+        return EpiResLN<2, 4, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale, e.res8, e.res8_plane, e.res8_scale};
     };
 
     // =============================================================== 1. fc + residual + LayerNorm (TM:92-93, 135)
