@@ -440,16 +440,16 @@ static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
         // B=128: what a large grid needs is more bytes in flight per CU, not fewer bytes per token.)
         static bool once = false;
         if (!once) {
-            HIP_TRY(allow_smem((tail_kernel<1, true, true>), tail_smem_bytes(1)));
-            HIP_TRY(allow_smem((tail_kernel<1, true, true, true>), tail_smem_bytes(1)));
+            HIP_TRY(allow_smem((tail_kernel<1, true, true>), tail_smem_bytes(1) + TAIL_PAR_BYTES));
+            HIP_TRY(allow_smem((tail_kernel<1, true, true, true>), tail_smem_bytes(1) + TAIL_PAR_BYTES));
             once = true;
         }
         // more than one workgroup per CU: the 256-register build, two workgroups per CU (measured at B=256: 190 against 235 us per
         // launch; at B=32 / 64, one workgroup per CU either way, the two builds take the same time)
         if (rows / 32 > 256)
-            tail_kernel<1, true, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+            tail_kernel<1, true, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1) + TAIL_PAR_BYTES, s>>>(ta);
         else
-            tail_kernel<1, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+            tail_kernel<1, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1) + TAIL_PAR_BYTES, s>>>(ta);
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -77,6 +77,7 @@ struct TailArgs {
 };
 
 static constexpr int tail_smem_bytes(int TT) { return TT * 32 * 1024 + 3 * TT * 4 * 32 * TT * 4; }  // chunk double buffer + epilogue scratch
+static constexpr int TAIL_PAR_BYTES = 10 * 512 * 4;  // the all-int8 build also stages its ten per-feature parameter vectors in LDS
 
 // Weight / activation fragments are fetched through buffer resources: address = SGPR base + SGPR offset + one VGPR
 // (plain global loads make hipcc build a 64-bit VGPR address per fragment and k-step: hundreds of registers of them).
@@ -323,6 +324,22 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
     auto as_ln = [&](const EpiResLN<2, 4, 0>& e) {
         return EpiResLN<2, 4, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale, e.res8, e.res8_plane, e.res8_scale};
     };
+    // All-int8 build: the ten per-feature parameter vectors of the three epilogues (weight row scales, biases, LayerNorm gains
+    // and shifts) are staged in LDS once per workgroup — the epilogues of a 32-token workgroup are load-latency chains, and an
+    // LDS read costs a tenth of an L2 round trip.  Visible after the first GEMM's prologue barrier.
+    const float *p_swfc = a.s_wfc, *p_sw1 = a.s_w1, *p_sw2 = a.s_w2;
+    if constexpr (FFN8 && FC8) {
+        float* par = (float*)(smem + tail_smem_bytes(TT));
+        const float* src[10] = {a.s_wfc, a.ln1.bias, a.ln1.gamma, a.ln1.beta, a.s_w1, a.relu8.bias, a.s_w2, a.ln2.bias, a.ln2.gamma, a.ln2.beta};
+        if (threadIdx.x < 128) {
+#pragma unroll
+            for (int v = 0; v < 10; ++v) *(float4*)(par + v * 512 + 4 * threadIdx.x) = *(const float4*)(src[v] + 4 * threadIdx.x);
+        }
+        p_swfc = par;
+        a.ln1.bias = par + 512; a.ln1.gamma = par + 1024; a.ln1.beta = par + 1536;
+        p_sw1 = par + 2048; a.relu8.bias = par + 2560;
+        p_sw2 = par + 3072; a.ln2.bias = par + 3584; a.ln2.gamma = par + 4096; a.ln2.beta = par + 4608;
+    }
 
     // =============================================================== 1. fc + residual + LayerNorm (TM:92-93, 135)
     if constexpr (FC8) {
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int j = 0; j < TT; ++j) i8_fold_finish(acc[i][j], a.s_wfc + wave * FT * 32 + i * 32 + 4 * (lane >> 5));
+            for (int j = 0; j < TT; ++j) i8_fold_finish(acc[i][j], p_swfc + wave * FT * 32 + i * 32 + 4 * (lane >> 5));
     } else {
         G::run(acc, a.o, a.o_plane, a.HD16, a.wfc, a.wfc_plane, act, tt0, wave, lane, [&] { mark(7); });
     }
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
             I8Acc q[FT][TT];
             ffn_gemm(q, a.ln1.q8, a.ln1.q8_plane, a.w1_8, 8);
             mark(3);
-            e8.template run<false, I8Acc, FT, TT>(q, a.s_w1, a.ln1.q8_scale, wave * FT * 32, tok0, lane, wave, 0, red);
+            e8.template run<false, I8Acc, FT, TT>(q, p_sw1, a.ln1.q8_scale, wave * FT * 32, tok0, lane, wave, 0, red);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
             I8Acc q[FT][TT];
             ffn_gemm(q, a.relu8.q8, a.relu8.q8_plane, a.w2_8, 9);
             mark(5);
-            i8_dequant_tile<false>(q, acc, a.s_w2, a.relu8.q8_scale, wave * FT * 32, tok0, lane);
+            i8_dequant_tile<false>(q, acc, p_sw2, a.relu8.q8_scale, wave * FT * 32, tok0, lane);
         }
         as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
         EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
