@@ -251,7 +251,7 @@ def main():
         fl_step = flops_per_window_step(T) * B
         i8 = args.precision in (8, 9) and 64 < T + 1 <= 128
         i8_long = args.precision in (8, 9) and T + 1 > 128   # int8 projections written as int8 images + separate int8 attention core
-        attn_name = "attn_layer_i8_kernel" if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
+        attn_name = "attn_layer_i8w_kernel" if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
         attn_peak = PEAK_I8_TOPS if (i8 or i8_long) else PEAK_BF16_TFLOPS
         attn_flops = Bl * 2 * (T + 1) * 512 * 3 * 1024 if i8_long else qkv_attn_flops_per_launch(Bl, T)
         attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None
@@ -259,8 +259,8 @@ def main():
         L = T + 1
         ms_step = 1e3 * el / K
         attn_roof = {
-            "bound": "mfma", "kernel": attn_name + (" (Q/K/V projections, softmax and PV of one window x head per workgroup, int8 slices; "
-                                                    "K, V and the probabilities stay in LDS/registers)" if i8 else
+            "bound": "mfma", "kernel": attn_name + (" (Q/K/V projections, softmax and PV of one window x head per 8-wave workgroup, int8 slices; "
+                                                    "K, V, Q and the probabilities stay in LDS/registers)" if i8 else
                                                     (" (Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8_kernel; "
                                                      "projection operations only)" if i8_long else " (fused Q/K/V projection + attention, split-bf16)")),
             "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if (i8 or i8_long) else "TFLOP/s",

@@ -13,6 +13,7 @@
 
 #include "attention.h"
 #include "attn_layer_i8.h"
+#include "attn_layer_i8w.h"
 #include "attn_core_i8.h"
 #include "common.h"
 #include "gemm.h"
@@ -46,7 +47,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ------------------------------------------------------------------------------------ context
 struct LayerDev {
     __bf16 *w_qkv, *w_fc, *w_1, *w_2;  // fragment-tiled, 2 planes each
-    int8_t* w_qkv8n;                   // i8x3 copy of w_qkv for attn_layer_i8_kernel: two slices, K in acc32 order
+    int8_t* w_qkv8n;                   // i8x3 copy of w_qkv for attn_layer_i8w_kernel: two slices, K in acc32 order
     float* s_qkv;                      // its row scales [3*HD]
     int8_t *w_1_8, *w_2_8;             // i8x3 copies of the FFN weights: two slices of [512][512], K in acc32 order
     float *s_1, *s_2;                  // their row scales [512]
@@ -593,10 +594,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             }
             static bool once = false;
             if (!once) {
-                HIP_TRY(allow_smem(attn_layer_i8_kernel, AL_SMEM_BYTES));
+                HIP_TRY(allow_smem(attn_layer_i8w_kernel, AL_SMEM_BYTES));
                 once = true;
             }
-            attn_layer_i8_kernel<<<dim3(nw * H), dim3(256), AL_SMEM_BYTES, s>>>(al);
+            attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AL_SMEM_BYTES, s>>>(al);
             HIP_TRY(hipGetLastError());
         } else if (fused_attn) {
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)

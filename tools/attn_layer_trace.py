@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of attn_layer_i8_kernel (perf-debug): per-workgroup timestamps at the phase boundaries."""
+"""Phase timeline of attn_layer_i8w_kernel (perf-debug): per-workgroup timestamps at the phase boundaries."""
 import ctypes as C
 import os
 import sys
@@ -12,11 +12,11 @@ from egoego_release_amd import _lib as _eglib
 _eglib.use_perfdebug_build()  # needs `python -m egoego_release_amd.build --perfdebug`
 from egoego_release_amd.model import CondGaussianDiffusion
 
-B, T = 256, 120
+B, T = int(os.environ.get("TT_B", 256)), 120
 cfg = ModelConfig(max_timesteps=T + 1)
 m = CondGaussianDiffusion(**cfg.ctor_kwargs())
 m.load_state_dict(make_weights(cfg, 0), strict=False)
-m.hip_precision = _lib.PREC_I8X3
+m.hip_precision = int(os.environ.get("KT_PREC", _lib.PREC_I8X3_FC))
 m = m.cuda()
 eng = m.hip_engine()
 lib = _lib.load()

@@ -10,7 +10,7 @@ B, T, L, HD, DM, D = 256, 120, 121, 1024, 512, 198
 PEAK_TF, PEAK_I8, PEAK_HBM = 2500.0, 5000.0, 8.0  # TFLOP/s bf16 dense, TOP/s int8 dense, TB/s (MI355X_MICROARCH.md)
 
 ALG = {  # kernel tag -> (what, algorithmic FLOPs per launch, algorithmic HBM bytes per launch)
-    "attn_layer_i8_kernel": ("Q/K/V projections + softmax + PV (one layer), int8 slices", B * (2 * L * DM * 3 * HD + 4 * L * L * HD),
+    "attn_layer_i8": ("Q/K/V projections + softmax + PV (one layer), int8 slices", B * (2 * L * DM * 3 * HD + 4 * L * L * HD),
                              2 * B * L * DM + 4 * B * L * HD + 3.2e6),
     "tail_kernel|layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; precision 9: all three contractions on int8 slices)", B * L * (2 * HD * DM + 4 * DM * DM), 4 * B * L * (HD + DM + DM) + 4.2e6),
     "EpiEmbed": ("embed GEMM + time token + pos-emb", 2 * B * T * 2 * D * DM, 4 * B * T * 2 * D + 4 * B * L * DM),
