@@ -282,14 +282,18 @@ def main():
                     if big_tail else
                     (" (the same three GEMMs per 32/64 tokens for small batches: weights streamed into registers, activations by LDS-DMA "
                      f"chunks; fc {'on int8 slices, one integer chain per head' if fc8 else 'split-bf16'}, {ffn_txt})"))
+        # the peak of the MFMAs the kernel issues: all int8 (precision 9), fc bf16 + FFN int8 (precision 8: the two halves of its
+        # FLOPs at 2.5 and 5 P, i.e. 3333 T together), all bf16 (precisions 3, 1)
+        tail_peak = PEAK_I8_TOPS if fc8 else (2.0 / (1.0 / PEAK_BF16_TFLOPS + 1.0 / PEAK_I8_TOPS) if args.precision == 8 else PEAK_BF16_TFLOPS)
+        tail_unit = "TOP/s (int8 MFMA, 2 per MAC)" if fc8 else ("TFLOP/s (fc on bf16 MFMAs, FFN on int8 MFMAs)" if args.precision == 8 else "TFLOP/s")
         tail_roof = {
             "bound": "mfma", "kernel": tail_name + tail_txt,
-            "achieved": tail_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (tail_ach / PEAK_BF16_TFLOPS) if tail_ach else None,
+            "achieved": tail_ach, "peak": tail_peak, "unit": tail_unit, "frac": (tail_ach / tail_peak) if tail_ach else None,
             "traffic": (traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
             "algorithmic_bytes": 4 * Bl * L * (1024 + 512 + 512) + 4.2e6,
             "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * ms_step) if t_n else None,
             "note": "measured like the attention-layer kernel; 3 MFMAs are issued per product (split-bf16: K=16 per MFMA; int8 slices: K=32 per "
-                    "MFMA at the same issue time), so the fraction is normalised by the bf16 peak although half the FLOPs run on int8 MFMAs"}
+                    "MFMA at the same issue time); normalised by the peak of the MFMAs the kernel actually issues"}
         dominant, other = (attn_roof, tail_roof) if (k_us or 0) >= (t_us or 0) else (tail_roof, attn_roof)
         out_json = {
             "metric": f"diffusion-steps/sec (B={B}, T={T}, 22-joint)",

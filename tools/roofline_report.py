@@ -12,7 +12,7 @@ PEAK_TF, PEAK_I8, PEAK_HBM = 2500.0, 5000.0, 8.0  # TFLOP/s bf16 dense, TOP/s in
 ALG = {  # kernel tag -> (what, algorithmic FLOPs per launch, algorithmic HBM bytes per launch)
     "attn_layer_i8": ("Q/K/V projections + softmax + PV (one layer), int8 slices", B * (2 * L * DM * 3 * HD + 4 * L * L * HD),
                              2 * B * L * DM + 4 * B * L * HD + 3.2e6),
-    "tail_kernel|layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; precision 9: all three contractions on int8 slices)", B * L * (2 * HD * DM + 4 * DM * DM), 4 * B * L * (HD + DM + DM) + 4.2e6),
+    "tail_kernel|layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; precision 9: all three contractions on int8 slices, int8 peak)", B * L * (2 * HD * DM + 4 * DM * DM), 4 * B * L * (HD + DM + DM) + 4.2e6),
     "EpiEmbed": ("embed GEMM + time token + pos-emb", 2 * B * T * 2 * D * DM, 4 * B * T * 2 * D + 4 * B * L * DM),
     "EpiOut": ("linear_out + DDPM posterior", 2 * B * T * DM * D, 4 * B * L * DM + 3 * 4 * B * T * D),
 }
@@ -29,7 +29,7 @@ def main():
         us = float(st["AverageNs"]) / 1e3
         tr = next((v for k, v in traffic.items() if any(t in k for t in tags)), None)
         hbm = tr["hbm_bytes_per_launch"] if tr else None
-        peak = PEAK_I8 if "i8" in tag else PEAK_TF  # (the tail is normalised by the bf16 peak whatever its operands: bench.py does the same)
+        peak = PEAK_I8 if ("i8" in tag or "tail_kernel" in tag) else PEAK_TF  # (precision 9: the tail issues int8 MFMAs only)
         rows.append((tags[0], what, us, float(st["Percentage"]), flops / us / 1e6, flops / us / 1e6 / peak, 3 * flops / us / 1e6 / peak,
                      abytes / 1e6, (hbm or 0) / 1e6, (hbm or 0) / us / 1e6))
     out = [f"# Per-kernel roofline, round {int(rnd[1:])} (B=256, T=120, precision i8x3: int8-slice attention layer and FFN + split-bf16 elsewhere; from the files in this directory)", "",
