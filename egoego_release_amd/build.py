@@ -34,7 +34,10 @@ def build(force=False, verbose=False, perfdebug=False, defines=(), tag=""):
     out = LIB.replace(".so", "_perfdebug" + (f"_{tag}" if tag else "") + ".so") if perfdebug else LIB
     if not force and not perfdebug and not is_stale():
         return out
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out]
+    # -ffp-contract=on: a multiply and an add fuse only where ONE source expression holds both (hipcc's default, "fast", also
+    # fuses across statements after inlining — then the bits of an epilogue depend on the kernel it was inlined into, and
+    # the same row computed by two tilings, e.g. a 32-window shard and the full batch, may differ in the last place)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-shared", "-fPIC", "-o", out]
     if perfdebug:
         cmd += ["-DEGOEGO_PERFDEBUG"] + [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]

@@ -434,23 +434,38 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return 0;
 }
-static int launch_tail(const TailArgs& ta, int rows, hipStream_t s) {
+#ifndef TAIL8_MAX_BLOCKS
+#define TAIL8_MAX_BLOCKS 256
+#endif
+static int launch_tail(const TailArgs& ta, int rows, hipStream_t s, bool resident = false) {
     if (ta.fc8) {
         // int8 fc: 32-token workgroups at every batch size.  (64-token ones — tail_kernel<2, true, true>, fc in two feature
         // passes, one workgroup per CU — measured slower: 250 against 235 us per launch at B=256, 0.94 against 0.80 ms per step at
         // B=128: what a large grid needs is more bytes in flight per CU, not fewer bytes per token.)
         static bool once = false;
         if (!once) {
-            HIP_TRY(allow_smem((tail_kernel<1, true, true>), tail_smem_bytes(1) + TAIL_PAR_BYTES));
             HIP_TRY(allow_smem((tail_kernel<1, true, true, true>), tail_smem_bytes(1) + TAIL_PAR_BYTES));
+            HIP_TRY(allow_smem((tail_kernel<1, true, true, false, 8>), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES));
+            HIP_TRY(allow_smem((tail_kernel<1, true, true, true, 4, true>), tail_smem_bytes(1) + TAIL_PAR_BYTES + TAIL_RES_BYTES));
+            HIP_TRY(allow_smem((tail_kernel<1, true, true, false, 8, true>), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES + TAIL_RES_BYTES));
             once = true;
         }
-        // more than one workgroup per CU: the 256-register build, two workgroups per CU (measured at B=256: 190 against 235 us per
-        // launch; at B=32 / 64, one workgroup per CU either way, the two builds take the same time)
-        if (rows / 32 > 256)
+        if (resident) {  // precision 9's product path: the FFN operands never leave the CU (tail_fused.h RES)
+            if (rows / 32 > TAIL8_MAX_BLOCKS)
+                tail_kernel<1, true, true, true, 4, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1) + TAIL_PAR_BYTES + TAIL_RES_BYTES, s>>>(ta);
+            else
+                tail_kernel<1, true, true, false, 8, true><<<dim3(rows / 32), dim3(512), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES + TAIL_RES_BYTES, s>>>(ta);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        // more than one workgroup per CU: the 256-register four-wave build, two workgroups per CU (measured at B=256: 190 against
+        // 235 us per launch of the 512-register four-wave build).  At most one workgroup per CU: the eight-wave build, the same
+        // 256-register waves as ONE workgroup (measured against the four-wave builds, which tie there: 31.5 against 39.5 us per
+        // launch at B=32, 0.316 against 0.344 ms per step; 0.387 against 0.415 at B=64; 0.304 against 0.332 at B=1)
+        if (rows / 32 > TAIL8_MAX_BLOCKS)
             tail_kernel<1, true, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1) + TAIL_PAR_BYTES, s>>>(ta);
         else
-            tail_kernel<1, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1) + TAIL_PAR_BYTES, s>>>(ta);
+            tail_kernel<1, true, true, false, 8><<<dim3(rows / 32), dim3(512), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES, s>>>(ta);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -706,7 +721,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 }
                 ta.stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
                 EG_DBG(ta.trace = g_trace;)
-                if (int r = launch_tail(ta, rows, s)) return r;
+                if (int r = launch_tail(ta, rows, s, act8_only)) return r;
                 if (last_dbg) return 0;
                 continue;
             }

@@ -19,6 +19,8 @@
 // MFMAs that consume them.  With NP == 2 each fragment pair costs three MFMAs (lo*hi, hi*lo, hi*hi); the int8-slice
 // form (accumulator type I8Acc) issues s2*s1, s1*s2 into one int32 accumulator and s1*s1 into a second.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef EGOEGO_ABLATE_MAINLOOP
@@ -495,6 +497,20 @@ EG_D void i8_fold_finish(f32x16& run, const float* sw8) {  // sw8 = weight row s
 }
 
 // =================================================================================== epilogues
+// A lane's 16 bytes of (k-block kb = 32 features, token tile j) in an LDS-resident int8 operand: the chunk buffers of
+// tail_fused.h's DirectGemm, [chunk = kb / 8][slice][token tile][kb % 8][1 KiB]; the second slice TT * 8 KiB further.
+template <int TT>
+EG_D char* lds_chunk_slot(char* base, int kb, int j, int lane) {
+    return base + (kb >> 3) * (2 * TT * 8192) + ((j * 8 + (kb & 7)) << 10) + lane * 16;
+}
+// int8 rows of a wave tile (FT feature tiles x one token tile) held in registers: the all-int8 tail keeps LayerNorm-1's rows
+// as LayerNorm-2's residual this way
+template <int FT>
+struct Rows8 {
+    u32x4 s1[FT], s2[FT];
+    float scale;
+};
+struct NoRows {};
 // Swapped accumulator geometry used below: for acc[ft][tt][r] of lane l (hf = l >> 5, col = l & 31)
 //   token   m = t0 + tt*32 + col
 //   feature f = f0 + ft*32 + 8*(r>>2) + 4*hf + (r&3)          (4 consecutive features per r>>2)
@@ -539,12 +555,17 @@ struct EpiTiled {
 // bias + ReLU -> the rows as int8 slices with one scale per row (i8x3 FFN: the hidden activations of TM:111 are the
 // int8 operand of the second conv).  The block must span all 512 hidden features (NWF * FT * 32 == 512): the row maximum
 // is taken in-lane over the wave's tiles, across the two halves by a shuffle and across the NWF waves through LDS.
+// lds_q8 != nullptr (the LDS-resident tail, tail_fused.h): the rows go to LDS instead, as the operand chunks of the next contraction
+// ([chunk = k-block / 8][slice][token tile][k-block % 8][1 KiB], token tile j of the block = token tile j of the wave tile), and
+// the row scales to lds_scale[token of the block]; q8 / q8_scale may then be null.
 template <int NWF, int BT>
 struct EpiReluQ8 {
     const float* bias;   // [512]
     int8_t* q8;          // fragment-tiled int8 rows [Mp][512], K in acc32 order; second slice at + q8_plane
     size_t q8_plane;
     float* q8_scale;     // [Mp]
+    char* lds_q8;
+    float* lds_scale;
     // q: the integer sums of an int8-slice contraction (I8Acc or I8One); sw / sa: weight-row and activation-row scales.
     // LEAN (256-register waves, two per SIMD): two sweeps over the INTEGER sums, one tile at a time (a tile's 16 scales and
     // 16 biases in registers; the fences keep hipcc from hoisting every tile's loads to the top): the first only takes the
@@ -601,7 +622,11 @@ struct EpiReluQ8 {
 #pragma unroll
             for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red[(j * NWF + w) * BT + (wt * TT + j) * 32 + col]);
             inv[j] = rmax > 0.f ? I8_QMAX / rmax : 0.f;
-            if (wf == 0 && hf == 0) q8_scale[t0 + j * 32 + col] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+            if (wf == 0 && hf == 0) {
+                const float sc = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+                if (q8_scale) q8_scale[t0 + j * 32 + col] = sc;
+                if (lds_scale) lds_scale[j * 32 + col] = sc;
+            }
         }
 #pragma unroll
         for (int i = 0; i < FT; ++i)
@@ -620,9 +645,16 @@ struct EpiReluQ8 {
                 for (int r = 0; r < 16; ++r) t[r] = v[r];
                 u32x4 s1, s2;
                 quant16(t, inv[j], s1, s2);
-                const size_t idx = acc_slot_i8(t0 + j * 32 + col, f0 + i * 32, hf, 16);
-                *(u32x4*)(q8 + idx) = s1;
-                *(u32x4*)(q8 + q8_plane + idx) = s2;
+                if (q8) {
+                    const size_t idx = acc_slot_i8(t0 + j * 32 + col, f0 + i * 32, hf, 16);
+                    *(u32x4*)(q8 + idx) = s1;
+                    *(u32x4*)(q8 + q8_plane + idx) = s2;
+                }
+                if (lds_q8) {
+                    char* d = lds_chunk_slot<TT>(lds_q8, (f0 >> 5) + i, j, lane);
+                    *(u32x4*)d = s1;
+                    *(u32x4*)(d + TT * 8192) = s2;
+                }
             }
     }
 };
@@ -721,8 +753,20 @@ struct EpiV {
 // bias + residual + LayerNorm(512) (+ padding-mask row multiply) -> fragment-tiled split-bf16.
 // Output projection of attention (TM:92-93, 135) and second FFN conv (TM:111-114, 139).
 // The block must span all 512 features (NWF * FT * 32 == 512).
+// Summation order of the two row reductions (sum, centred squares), the same for every tiling so that a row's bits do not depend on
+// the kernel that computes it: one partial per PAIR of consecutive feature tiles (64 features: the 32 values of a lane in tile, register
+// order, + the other half-wave's), the 8 pair partials of a row combined as ((q0 + q1) + q2) + q3 with q_w = pair 2w + pair 2w+1.
+// A wave holding 4 tiles (NWF = 4) owns one q, a wave holding 2 (NWF = 8: the eight-wave small-grid tail) one pair.
 template <int NP, int NWF, int BT>
 struct EpiResLN {
+    static_assert(NWF == 4 || NWF == 8, "4 waves of 4 feature tiles or 8 waves of 2");
+    // the row total from the per-wave partials in LDS
+    static EG_D float combine(const float* red, int slot) {
+        float q[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) q[w] = NWF == 4 ? red[slot + w * BT] : red[slot + 2 * w * BT] + red[slot + (2 * w + 1) * BT];
+        return ((q[0] + q[1]) + q[2]) + q[3];
+    }
     const float* bias;
     const __bf16* res;  // fragment-tiled [Mp][512]
     size_t res_plane;
@@ -740,9 +784,16 @@ struct EpiResLN {
     const int8_t* res8;
     size_t res8_plane;
     const float* res8_scale;
-    template <int FT, int TT>
-    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem) const {
-        static_assert(NWF * FT * 32 == 512, "LayerNorm epilogue needs the whole 512-wide row in the block");
+    // optional (the LDS-resident tail): the int8 rows ALSO / ONLY into LDS as the next contraction's operand chunks (see EpiReluQ8)
+    char* lds_q8;
+    float* lds_scale;
+    // rr: the residual as int8 rows in registers (instead of res / res8); keep: receives the int8 rows this call produces
+    template <int FT, int TT, class ResR = NoRows, class KeepR = NoRows>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem, const ResR* rr = nullptr,
+                        KeepR* keep = nullptr) const {
+        constexpr bool RES_REG = !std::is_same<ResR, NoRows>::value, KEEP = !std::is_same<KeepR, NoRows>::value;
+        static_assert((!RES_REG && !KEEP) || TT == 1, "register rows: one token tile");
+        static_assert(NWF * FT * 32 == 512 && (FT == 2 || FT == 4), "LayerNorm epilogue needs the whole 512-wide row in the block");
         const int hf = lane >> 5, col = lane & 31;
         float* red1 = (float*)smem;     // [TT][NWF][BT]  per-wave partial sums
         float* red2 = red1 + TT * NWF * BT;
@@ -757,23 +808,25 @@ struct EpiResLN {
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
             slot[j] = (j * NWF) * BT + (wt * TT + j) * 32 + col;
-            float s1 = 0.f;
-            if (res8) {
-                const float rs = res8_scale[m];
+            float s1 = 0.f, pp[FT / 2];
+            if (RES_REG || res8) {
+                float rs;
+                if constexpr (RES_REG) rs = rr->scale; else rs = res8_scale[m];
 #pragma unroll
                 for (int i = 0; i < FT; ++i) {
-                    const size_t idx8 = acc_slot_i8(m, f0 + i * 32, hf, 16);
                     float r[16];
-                    dequant16(*(const u32x4*)(res8 + idx8), *(const u32x4*)(res8 + res8_plane + idx8), rs, r);
+                    if constexpr (RES_REG) {
+                        dequant16(rr->s1[i], rr->s2[i], rs, r);
+                    } else {
+                        const size_t idx8 = acc_slot_i8(m, f0 + i * 32, hf, 16);
+                        dequant16(*(const u32x4*)(res8 + idx8), *(const u32x4*)(res8 + res8_plane + idx8), rs, r);
+                    }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 b4 = *(const float4*)(bias + f0 + i * 32 + 8 * g + 4 * hf);
                         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            acc[i][j][4 * g + c] += bb[c] + r[4 * g + c];
-                            s1 += acc[i][j][4 * g + c];
-                        }
+                        for (int c = 0; c < 4; ++c) acc[i][j][4 * g + c] += bb[c] + r[4 * g + c];
                     }
                 }
             } else
@@ -795,31 +848,41 @@ struct EpiResLN {
                     }
                     const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        acc[i][j][8 * jj + c] += bb[c] + r[c];
-                        s1 += acc[i][j][8 * jj + c];
-                    }
+                    for (int c = 0; c < 8; ++c) acc[i][j][8 * jj + c] += bb[c] + r[c];
                 }
-            s1 += __shfl_xor(s1, 32);
+#pragma unroll
+            for (int i2 = 0; i2 < FT / 2; ++i2) {
+                float p = 0.f;
+#pragma unroll
+                for (int i = 2 * i2; i < 2 * i2 + 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p += acc[i][j][r];
+                pp[i2] = p + __shfl_xor(p, 32);
+            }
+            s1 = pp[0];
+            if (FT == 4) s1 += pp[FT / 2 - 1];
             if (hf == 0) red1[slot[j] + wf * BT] = s1;
         }
         __syncthreads();
         // ---- biased variance of the centred values (two-pass, like the reference's LayerNorm)
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
-            float sm = 0.f;
+            mean[j] = combine(red1, slot[j]) * (1.0f / 512.0f);
+            float pp[FT / 2];
 #pragma unroll
-            for (int w = 0; w < NWF; ++w) sm += red1[slot[j] + w * BT];
-            mean[j] = sm * (1.0f / 512.0f);
-            float s2 = 0.f;
+            for (int i2 = 0; i2 < FT / 2; ++i2) {
+                float p = 0.f;
 #pragma unroll
-            for (int i = 0; i < FT; ++i)
+                for (int i = 2 * i2; i < 2 * i2 + 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = acc[i][j][r] - mean[j];
-                    s2 += d * d;
-                }
-            s2 += __shfl_xor(s2, 32);
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = acc[i][j][r] - mean[j];
+                        p += d * d;
+                    }
+                pp[i2] = p + __shfl_xor(p, 32);
+            }
+            float s2 = pp[0];
+            if (FT == 4) s2 += pp[FT / 2 - 1];
             if (hf == 0) red2[slot[j] + wf * BT] = s2;
         }
         __syncthreads();
@@ -827,9 +890,7 @@ struct EpiResLN {
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
-            float var = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWF; ++w) var += red2[slot[j] + w * BT];
+            const float var = combine(red2, slot[j]);
             rstd[j] = 1.0f / sqrtf(var * (1.0f / 512.0f) + eps);
             const float mk = row_mask ? row_mask[m] : 1.0f;
             amax[j] = 0.f;
@@ -857,12 +918,12 @@ struct EpiResLN {
                         if (NP == 2) *(u32x4*)(out + out_plane + idx) = lo;
                     }
                 }
-            if (q8) {
+            if (q8 || lds_q8) {
                 amax[j] = fmaxf(amax[j], __shfl_xor(amax[j], 32));
                 if (hf == 0) red3[slot[j] + wf * BT] = amax[j];
             }
         }
-        if (q8) {
+        if (q8 || lds_q8) {
             // row maximum over the 512 features -> one scale per token -> two int8 slices per value
             __syncthreads();
 #pragma unroll
@@ -872,7 +933,12 @@ struct EpiResLN {
 #pragma unroll
                 for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red3[slot[j] + w * BT]);
                 const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
-                if (wf == 0 && hf == 0) q8_scale[m] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+                const float sc = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+                if (wf == 0 && hf == 0) {
+                    if (q8_scale) q8_scale[m] = sc;
+                    if (lds_scale) lds_scale[(wt * TT + j) * 32 + col] = sc;
+                }
+                if constexpr (KEEP) keep->scale = sc;
 #pragma unroll
                 for (int i = 0; i < FT; ++i) {
                     float v[16];
@@ -880,9 +946,20 @@ struct EpiResLN {
                     for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
                     u32x4 s1, s2;
                     quant16(v, inv, s1, s2);
-                    const size_t idx = acc_slot_i8(m, f0 + i * 32, hf, 16);
-                    *(u32x4*)(q8 + idx) = s1;
-                    *(u32x4*)(q8 + q8_plane + idx) = s2;
+                    if (q8) {
+                        const size_t idx = acc_slot_i8(m, f0 + i * 32, hf, 16);
+                        *(u32x4*)(q8 + idx) = s1;
+                        *(u32x4*)(q8 + q8_plane + idx) = s2;
+                    }
+                    if (lds_q8) {
+                        char* d = lds_chunk_slot<TT>(lds_q8, (f0 >> 5) + i, j, lane);
+                        *(u32x4*)d = s1;
+                        *(u32x4*)(d + TT * 8192) = s2;
+                    }
+                    if constexpr (KEEP) {
+                        keep->s1[i] = s1;
+                        keep->s2[i] = s2;
+                    }
                 }
             }
         }

@@ -37,6 +37,13 @@
 #ifndef TAIL_RING_IO
 #define TAIL_RING_IO 4
 #endif
+// weight-ring depth of the FFN contractions of the eight-wave tail (its fc keeps 4: the fp32 running sums need the registers)
+#ifndef TAIL8_RING
+#define TAIL8_RING 4
+#endif
+#ifndef TAIL8_RING_FC
+#define TAIL8_RING_FC 4
+#endif
 
 struct TailArgs {
     // fc + residual + LayerNorm (TM:92-93, 135)
@@ -76,7 +83,7 @@ struct TailArgs {
     EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][32] phase timestamps or nullptr
 };
 
-static constexpr int tail_smem_bytes(int TT) { return TT * 32 * 1024 + 3 * TT * 4 * 32 * TT * 4; }  // chunk double buffer + epilogue scratch
+static constexpr int tail_smem_bytes(int TT, int NWV = 4) { return TT * 32 * 1024 + 3 * TT * NWV * 32 * TT * 4; }  // chunk double buffer + epilogue scratch
 static constexpr int TAIL_PAR_BYTES = 10 * 512 * 4;  // the all-int8 build also stages its ten per-feature parameter vectors in LDS
 
 // Weight / activation fragments are fetched through buffer resources: address = SGPR base + SGPR offset + one VGPR
@@ -222,12 +229,13 @@ struct TailChunk {
 // chunk double buffer in LDS (TT * 32 KiB).  Feature tile i of wave `wave` is tile wave * FT + i of W.
 // I8: int8-slice operands ([R/32][K/32][2][32][16] byte planes, the two slices `*_plane` bf16-element units = bytes / 2
 // apart; K16 then counts 32-wide k-blocks) accumulated into I8Acc pairs.
-template <int FT, int TT, int RING, bool REM2 = false, bool I8 = false>
+// NWAVES: waves of the workgroup (4, or the 8 of the eight-wave all-int8 tail): they share the LDS-DMA pieces of a chunk.
+template <int FT, int TT, int RING, bool REM2 = false, bool I8 = false, int NWAVES = 4>
 struct DirectGemm {
     using AccT = typename std::conditional<I8, I8Acc, f32x16>::type;
     static constexpr int NW = 2 * FT, PD = RING - 1;
     static constexpr int CH_PLANE = TT * 8 * 1024, CH_BYTES = 2 * CH_PLANE;  // chunk buffer: [plane][t-tile][8 k-blocks][1 KiB]
-    static constexpr int DMA_PIECES = 4 * TT;                                // 1-KiB pieces of a chunk per wave
+    static constexpr int DMA_PIECES = 16 * TT / NWAVES;                      // 1-KiB pieces of a chunk per wave
     static constexpr int SMEM_BYTES = 2 * CH_BYTES;
 
     struct NoPost {
@@ -287,6 +295,47 @@ struct DirectGemm {
         post(NQ - 1);
         __syncthreads();  // every wave is done with the chunk buffers before the next GEMM's first DMA
     }
+
+    // The same contraction with the WHOLE activation operand already in LDS: K = 16 k-blocks of 32 (the 512-wide int8 rows of
+    // the FFN contractions) are exactly the two chunk buffers, written there by the previous epilogue (gemm.h lds_chunk_slot)
+    // instead of going to memory and coming back by LDS-DMA.  No DMA, no barrier inside: the caller's barrier after the
+    // epilogue's LDS writes opens the loop, and the caller's next barrier closes it (before anything overwrites the buffers).
+    // Same k order, same MFMA order: same integers.  w_primed: the first PD k-steps of weights are already in the ring (issued
+    // by prime() before the epilogue, whose latency then hides their fetch).
+    static EG_D void prime(i32x4 (&wq)[RING][NW], const __bf16* w, size_t w_plane, int K16, int wt0, int lane) {
+        const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4);
+        const unsigned wpb = (unsigned)(w_plane * 2);
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) wq[k][2 * i + sl] = tail_load(wr, lane * 16, sl * wpb + (unsigned)(((wt0 + i) * K16 + k) << 10));
+    }
+    template <class Mark>
+    static EG_D void run_resident(AccT (&acc)[FT][TT], i32x4 (&wq)[RING][NW], const __bf16* w, size_t w_plane, const char* act, int lane, Mark mark,
+                                  int wt0) {
+        static_assert(!REM2, "two whole chunks");
+        constexpr int K16 = 16;
+        const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4);
+        const unsigned wpb = (unsigned)(w_plane * 2);
+        auto w_offsets = [&](int kb, unsigned (&out)[NW]) {
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) out[2 * i + sl] = sl * wpb + (unsigned)(((wt0 + i) * K16 + kb) << 10);
+        };
+        unsigned wcur[NW], wnext[NW];
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
+        mark();
+        w_offsets(0, wcur);
+        w_offsets(8, wnext);
+        TailChunk<FT, TT, RING, false, 0, 8, I8>::run(acc, wq, wr, wcur, wnext, act, CH_PLANE, lane, [](int) {});
+        TailChunk<FT, TT, RING, true, 0, 8, I8>::run(acc, wq, wr, wnext, wnext, act + CH_BYTES, CH_PLANE, lane, [](int) {});
+    }
 };
 
 // (Measured and NOT kept for B = 256: the same kernel with 2 ring slots, 256 registers and two co-resident 64-token workgroups per
@@ -298,10 +347,24 @@ struct DirectGemm {
 // lone workgroup's weight stream is latency-bound (bytes in flight / L2 latency): a second resident workgroup doubles the bytes
 // in flight and fills the other's epilogues.  Every contraction then runs its 4 feature tiles per wave in two passes of 2
 // (I8Acc pairs of 2 tiles + a 4-slot weight ring = 128 registers); integer sums and float operations are unchanged: same bits.
-template <int TT, bool FFN8, bool FC8 = false, bool W2 = false>
-__global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
+// NWV = 8 (int8 fc + FFN only): ONE eight-wave workgroup per CU, two 256-register waves per SIMD, a wave owning 64 features — for grids
+// of at most one workgroup per CU (every shard of the 8- and 4-GPU splits of BASELINE configs[2]), where a workgroup is a serial
+// chain and the chip is not full: a SIMD's second wave issues its weight loads and MFMAs in the first one's waits, and the three
+// epilogues (load-latency chains over a wave's feature tiles) are split over twice the waves.  Same integers, same float operations
+// per value, LayerNorm partials combined in the order every tiling uses (gemm.h EpiResLN): same bits.
+// RES (int8 fc + FFN only; the product path of precision 9, whose inter-kernel activations are int8 rows only): the FFN operands stay
+// on the CU.  LayerNorm-1 writes its int8 rows into the two LDS chunk buffers — for K = 512 they ARE the whole operand of FFN-1
+// — and keeps them in registers as LayerNorm-2's residual; FFN-1's epilogue writes the hidden rows over them for FFN-2.  Neither
+// tensor goes to memory (2 x 33 MB written and read back per launch at B=256 otherwise), no s_waitcnt vmcnt(0) + LDS-DMA round trip
+// stands between a LayerNorm and the contraction behind it, and the next contraction's first weight fragments are fetched
+// before the epilogue that precedes it.  Same integers, same float operations: same bits as the memory round trip.
+static constexpr int TAIL_RES_BYTES = 256;  // two [32] row-scale vectors in LDS
+template <int TT, bool FFN8, bool FC8 = false, bool W2 = false, int NWV = 4, bool RES = false>
+__global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_kernel(TailArgs a) {
+    static_assert(!RES || (FFN8 && FC8 && TT == 1), "LDS-resident FFN operands: the all-int8 32-token tail");
     static_assert(!W2 || (FFN8 && FC8 && TT == 1), "the two-workgroups-per-CU build exists for the all-int8 32-token tail");
-    constexpr int TOK = 32 * TT, FT = 4;
+    static_assert(NWV == 4 || (NWV == 8 && FFN8 && FC8 && TT == 1 && !W2), "the eight-wave build exists for the all-int8 32-token tail");
+    constexpr int TOK = 32 * TT, FT = 16 / NWV;
     using G = DirectGemm<FT, TT, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const act = smem;
@@ -322,14 +385,14 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
     f32x16 acc[FT][TT];
     // epilogue structs carry the large-batch kernels' code; only the tokens-per-block template argument differs
     auto as_ln = [&](const EpiResLN<2, 4, 0>& e) {
-        return EpiResLN<2, 4, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale, e.res8, e.res8_plane, e.res8_scale};
+        return EpiResLN<2, NWV, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale, e.res8, e.res8_plane, e.res8_scale};
     };
     // All-int8 build: the ten per-feature parameter vectors of the three epilogues (weight row scales, biases, LayerNorm gains
     // and shifts) are staged in LDS once per workgroup — the epilogues of a 32-token workgroup are load-latency chains, and an
     // LDS read costs a tenth of an L2 round trip.  Visible after the first GEMM's prologue barrier.
     const float *p_swfc = a.s_wfc, *p_sw1 = a.s_w1, *p_sw2 = a.s_w2;
     if constexpr (FFN8 && FC8) {
-        float* par = (float*)(smem + tail_smem_bytes(TT));
+        float* par = (float*)(smem + tail_smem_bytes(TT, NWV));
         const float* src[10] = {a.s_wfc, a.ln1.bias, a.ln1.gamma, a.ln1.beta, a.s_w1, a.relu8.bias, a.s_w2, a.ln2.bias, a.ln2.gamma, a.ln2.beta};
         if (threadIdx.x < 128) {
 #pragma unroll
@@ -347,8 +410,8 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
         // A wave's 4 feature tiles go in FP passes of 4 / FP tiles: with 64 tokens per workgroup (TT = 2) the I8Acc pairs of
         // all 8 tiles next to their 8 running-sum tiles would exceed the register file, so the two feature halves run one
         // after the other (the activation chunks are streamed twice, the weights once either way).
-        constexpr int FP = (W2 || TAIL_RING1 == 8) ? 2 : TT, FTP = FT / FP;
-        using GF = DirectGemm<FTP, TT, (W2 ? 4 : TAIL_RING1), false, true>;
+        constexpr int FP = NWV == 8 ? 1 : ((W2 || TAIL_RING1 == 8) ? 2 : TT), FTP = FT / FP;
+        using GF = DirectGemm<FTP, TT, (NWV == 8 ? TAIL8_RING_FC : (W2 ? 4 : TAIL_RING1)), false, true, NWV>;
         const int col = lane & 31;
 #pragma unroll
         for (int i = 0; i < FT; ++i)
@@ -381,6 +444,54 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
         G::run(acc, a.o, a.o_plane, a.HD16, a.wfc, a.wfc_plane, act, tt0, wave, lane, [&] { mark(7); });
     }
     mark(1);
+    if constexpr (RES) {
+        constexpr int FP8 = W2 ? 2 : 1, FTP8 = FT / FP8, RING8 = NWV == 8 ? TAIL8_RING : 4;
+        using G8 = DirectGemm<FTP8, TT, RING8, false, true, NWV>;
+        float* const ls1 = (float*)(smem + tail_smem_bytes(TT, NWV) + TAIL_PAR_BYTES);  // row scales of the LayerNorm-1 rows, of the hidden rows
+        float* const ls2 = ls1 + 32;
+        i32x4 wq[RING8][2 * FTP8];
+        Rows8<FT> h1;
+        // the contraction of all FP8 feature passes over the LDS-resident operand; pass 0's first weights were primed by the caller
+        auto ffn_resident = [&](I8Acc (&q)[FT][TT], const int8_t* w8, int mk) {
+#pragma unroll
+            for (int fp = 0; fp < FP8; ++fp) {
+                if (fp) G8::prime(wq, (const __bf16*)w8, a.w8_plane / 2, 16, wave * FT + fp * FTP8, lane);
+                G8::run_resident(*(I8Acc(*)[FTP8][TT]) & q[fp * FTP8], wq, (const __bf16*)w8, a.w8_plane / 2, act, lane, [&] { mark(mk); }, wave * FT + fp * FTP8);
+            }
+        };
+        G8::prime(wq, (const __bf16*)a.w1_8, a.w8_plane / 2, 16, wave * FT, lane);
+        {
+            auto e = as_ln(a.ln1);
+            e.q8 = nullptr; e.q8_scale = nullptr;
+            e.lds_q8 = act; e.lds_scale = ls1;
+            e.template run<FT, TT, NoRows, Rows8<FT>>(acc, wave * FT * 32, tok0, lane, wave, 0, red, nullptr, &h1);
+        }
+        __syncthreads();  // the rows and their scales are in LDS
+        mark(2);
+        I8Acc q[FT][TT];
+        ffn_resident(q, a.w1_8, 8);
+        mark(3);
+        G8::prime(wq, (const __bf16*)a.w2_8, a.w8_plane / 2, 16, wave * FT, lane);
+        {
+            // (the barrier inside the epilogue, between its row-maximum exchange and its stores, is also what lets the stores
+            // overwrite the LayerNorm-1 rows: every wave has left its k-loop by then)
+            const EpiReluQ8<NWV, TOK> e{a.relu8.bias, nullptr, 0, nullptr, act, ls2};
+            e.template run<false, I8Acc, FT, TT>(q, p_sw1, ls1, wave * FT * 32, 0, lane, wave, 0, red);
+        }
+        __syncthreads();
+        mark(4);
+        ffn_resident(q, a.w2_8, 9);
+        mark(5);
+        i8_dequant_tile<false>(q, acc, p_sw2, ls2, wave * FT * 32, 0, lane);
+        {
+            auto e = as_ln(a.ln2);
+            e.res8 = nullptr;
+            e.template run<FT, TT, Rows8<FT>, NoRows>(acc, wave * FT * 32, tok0, lane, wave, 0, red, &h1, nullptr);
+        }
+        EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
+        mark(6);
+        return;
+    }
     as_ln(a.ln1).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
     // this workgroup's LayerNorm-1 rows must have reached L2 before its LDS-DMAs of them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -392,9 +503,9 @@ __global__ __launch_bounds__(256, (W2 ? 2 : 1)) void tail_kernel(TailArgs a) {
     if constexpr (FFN8) {
         // int8 slices, one pass into I8Acc pairs (a lone wave per SIMD has the registers): the integer sums — and so every
         // bit downstream — equal the two-pass one-accumulator form of the large-batch kernel (layer_tail_i8_kernel)
-        constexpr int FP8 = (W2 || (TT == 1 && TAIL_RING1 == 8)) ? 2 : 1, FTP8 = FT / FP8;  // feature passes of the FFN contractions (two of 2 tiles where the ring is deep or the registers few)
-        using G8 = DirectGemm<FTP8, TT, (TT == 2 ? 2 : (W2 ? 4 : TAIL_RING1)), false, true>;  // TT = 2: 256 accumulator registers, so a 2-slot weight ring
-        const EpiReluQ8<4, TOK> e8{a.relu8.bias, a.relu8.q8, a.relu8.q8_plane, a.relu8.q8_scale};
+        constexpr int FP8 = NWV == 8 ? 1 : ((W2 || (TT == 1 && TAIL_RING1 == 8)) ? 2 : 1), FTP8 = FT / FP8;  // feature passes of the FFN contractions (two of 2 tiles where the ring is deep or the registers few)
+        using G8 = DirectGemm<FTP8, TT, (TT == 2 ? 2 : (W2 ? 4 : (NWV == 8 ? TAIL8_RING : TAIL_RING1))), false, true, NWV>;  // TT = 2: 256 accumulator registers, so a 2-slot weight ring
+        const EpiReluQ8<NWV, TOK> e8{a.relu8.bias, a.relu8.q8, a.relu8.q8_plane, a.relu8.q8_scale};
         auto ffn_gemm = [&](I8Acc (&q)[FT][TT], const int8_t* in8, size_t in_plane_bytes, const int8_t* w8, int mk) {
 #pragma unroll
             for (int fp = 0; fp < FP8; ++fp)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "egoego_release_amd", "csrc")
 flt = [a for a in sys.argv[1:] if not a.startswith("-D")]
 defs = [a for a in sys.argv[1:] if a.startswith("-D")]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-shared", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
        "-o", "/tmp/_kr.so", os.path.join(CSRC, "egoego_hip.hip")] + defs
 out = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC).stderr
 cur = None
