@@ -569,10 +569,12 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                                            w.h_plane, i8_path ? w.hA_scale : nullptr, io.state, io.ts}};
             if (int r = launch_embed_tt<1>(ea, rows, s)) return r;
         } else if (i8_path) {
-            // 512-feature x 64-token blocks (two workgroups per CU): the epilogue sees whole rows and also writes them as int8 slices
-            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
-            EpiEmbed<NP, 4, 64> e{c->b_embed, c->pe, c->tt_table, w.t_idx, embed_out, w.h_plane, g.Lr, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
-            if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
+            // 512-feature x 128-token blocks, eight waves, one workgroup per CU (the epilogue sees whole rows and also writes them as
+            // int8 slices): the 16 weight tiles of a k-step are staged once for 4 token tiles instead of once per 2 (64-token
+            // blocks, two per CU: 53.7 us per launch at B=256 against 51.8)
+            GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 128, row0 / 128 EG_DBG(, g_ablate, g_trace)};
+            EpiEmbed<NP, 4, 128> e{c->b_embed, c->pe, c->tt_table, w.t_idx, embed_out, w.h_plane, g.Lr, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
+            if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
         } else {
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
             EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lr, g.T, g.B, nullptr, 0, nullptr, io.state, io.ts};

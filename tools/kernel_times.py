@@ -19,14 +19,17 @@ m.load_state_dict(make_weights(cfg, 0), strict=False)
 m.hip_precision = prec
 m = m.cuda()
 eng = m.hip_engine()
+if "KT_ABLATE" in os.environ:  # perf-debug build: 2 = the ring-GEMM kernels (embed / linear_out at large grids) skip their epilogues
+    _lib.load().egoego_debug_ablate(int(os.environ["KT_ABLATE"]))
 x = torch.randn(B, T, 198, device="cuda")
 xc = torch.randn(B, T, 198, device="cuda")
-eng.sample_loop_(x, xc, 999, 3, noise_mode=_lib.NOISE_PHILOX)
+NM = int(os.environ.get("KT_NOISE", _lib.NOISE_PHILOX))  # 1 = in-kernel Philox (default), 2 = no noise (what the generator costs the out kernel)
+eng.sample_loop_(x, xc, 999, 3, noise_mode=NM)
 torch.cuda.synchronize()
 tot = 0.0
 for k in ("embed", "qkv", "attn", "fc_ln", "ffn1", "ffn2_ln", "out"):
     eng.profile_begin(k)
-    eng.sample_loop_(x, xc, 900, 5, noise_mode=_lib.NOISE_PHILOX)
+    eng.sample_loop_(x, xc, 900, 5, noise_mode=NM)
     us, n = eng.profile_end()
     per_step = us * n / 5
     tot += per_step
