@@ -179,15 +179,20 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
         if (hf == 0) red[kh * 128 + qt3 * 32 + col] = mx;
         __syncthreads();
         mx = fmaxf(red[qt3 * 32 + col], red[128 + qt3 * 32 + col]);  // (key 0 always exists: finite)
-        float sum = 0.f;
+        // row sum of the probabilities, in one order for every form of this kernel: per key tile (16 values of a lane in register
+        // order + the other half-wave's), then (tile 0 + tile 1) + (tile 2 + tile 3)
+        float st[2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt) {
+            float s1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 p[kt][r] = __builtin_amdgcn_exp2f(p[kt][r] - mx);
-                sum += p[kt][r];
+                s1 += p[kt][r];
             }
-        sum += __shfl_xor(sum, 32);
+            st[kt] = s1 + __shfl_xor(s1, 32);
+        }
+        const float sum = st[0] + st[1];
         if (hf == 0) psum[kh * 128 + qt3 * 32 + col] = sum;  // read in phase 5, behind the V projection's barriers
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {

@@ -14,6 +14,7 @@
 #include "attention.h"
 #include "attn_layer_i8.h"
 #include "attn_layer_i8w.h"
+#include "attn_layer_i8h.h"
 #include "attn_core_i8.h"
 #include "common.h"
 #include "gemm.h"
@@ -434,6 +435,12 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return 0;
 }
+// two half-query workgroups per (window, head) while they fill at most HALF the CUs (measured, ms per step at B = 1 / 16 / 32:
+// 0.269 / 0.268 / 0.303 with them, 0.292 / 0.295 / 0.297 without: with every CU busy the redundant K / V projections cost more than
+// the shorter chain saves)
+#ifndef ATTN_HALF_MAX_BLOCKS
+#define ATTN_HALF_MAX_BLOCKS 128
+#endif
 #ifndef TAIL8_MAX_BLOCKS
 #define TAIL8_MAX_BLOCKS 256
 #endif
@@ -612,9 +619,14 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             static bool once = false;
             if (!once) {
                 HIP_TRY(allow_smem(attn_layer_i8w_kernel, AL_SMEM_BYTES));
+                HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
                 once = true;
             }
-            attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AL_SMEM_BYTES, s>>>(al);
+            // a quarter of the CUs' worth of (window, head) pairs or fewer: two workgroups per pair, half the queries each (attn_layer_i8h.h)
+            if (nw * H * 2 <= ATTN_HALF_MAX_BLOCKS)
+                attn_layer_i8h_kernel<<<dim3(nw * H * 2), dim3(512), AL_SMEM_BYTES, s>>>(al);
+            else
+                attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AL_SMEM_BYTES, s>>>(al);
             HIP_TRY(hipGetLastError());
         } else if (fused_attn) {
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)

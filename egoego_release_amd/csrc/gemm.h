@@ -84,10 +84,11 @@ struct GemmCfg {
     static constexpr int AT = NWT * TT;  // activation (token) tiles per block
     static constexpr int BF = WT * 32, BT = AT * 32;
     static constexpr int NBLK = (WT + AT) * NP * KS;  // 1 KiB fragment blocks per stage
-    static constexpr int NCH = NBLK / NW;             // 16-byte chunks per thread per stage
+    static constexpr int NCH = (NBLK + NW - 1) / NW;  // 16-byte chunks per thread per stage
+    // (NBLK % NW != 0: the waves that would run out of blocks stage the stage's LAST block once more — same bytes to the same
+    // place — so that every wave has the same number of loads in flight, which is what the counted waits assume)
     static constexpr int STAGE_BYTES = NBLK * 1024;
     static constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;
-    static_assert(NBLK % NW == 0, "stage blocks must divide evenly over the waves");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4 && 2 * NCH < 64, "ring depth / vmcnt range");
 };
 
@@ -162,9 +163,11 @@ struct GemmBody {
 
         // Per-thread source pointers of this stage's chunks (wave-uniform base + lane).
         const u32x4* gp[NCH];
+        int dsto[NCH];  // byte offset of chunk j's block inside a stage
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const int blk = j * NW + wave;
+            const int blk = min(j * NW + wave, C::NBLK - 1);
+            dsto[j] = blk * 1024;
             const int ks = blk % KS, t2 = blk / KS;
             const u32x4* base;
             if (t2 < WT * NP) {
@@ -222,10 +225,10 @@ struct GemmBody {
             }
         };
         auto issue_one = [&](int stage, int slot, int j) {
-            char* dst = smem + (size_t)slot * C::STAGE_BYTES + (size_t)wave * 1024;
+            char* dst = smem + (size_t)slot * C::STAGE_BYTES;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(gp[j] + (size_t)stage * KS * 64),
-                (__attribute__((address_space(3))) void*)(dst + (size_t)j * NW * 1024), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(dst + dsto[j]), 16, 0, 0);
         };
         // MFMAs of one half (FH x TT accumulator triples, part-major).  DMA instruction q of (stage, slot) is issued
         // after MFMA q - q0, so the DMA issue cost is paid in the shadow of the matrix pipe.

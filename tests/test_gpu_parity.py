@@ -327,6 +327,30 @@ def test_batch_size_invariance_covers_large_batch_kernels(prec):
     assert (a[:3] - b).abs().max().item() <= 1e-6
 
 
+def test_small_grid_kernels_give_the_bits_of_the_large_grid_ones():
+    """Default precision: which kernels run depends on the batch — up to 16 windows two half-query attention workgroups per
+    (window, head) and the eight-wave tail, up to 64 windows the full attention workgroup and the eight-wave tail, beyond that
+    the two-workgroups-per-CU tail, embed / linear_out on the direct-operand kernels up to 128 windows — and all of them must
+    produce the SAME bits for a window (integer contractions; one summation order for the LayerNorm and softmax row sums)."""
+    cfg, sd, m = _model(precision=_lib.PREC_I8X3_FC)
+    eng = m.hip_engine()
+    g = torch.Generator().manual_seed(5)
+    B = 256
+    x = torch.randn(B, 120, 198, generator=g).cuda()
+    xc = torch.randn(B, 120, 198, generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    big = m.denoise(x, t, xc)
+    for n in (1, 3, 16, 24, 64, 100):
+        small = m.denoise(x[:n].contiguous(), t[:n].contiguous(), xc[:n].contiguous())
+        assert torch.equal(small, big[:n]), n
+    a = x.clone()
+    eng.sample_loop_(a, xc, 999, 5, noise_mode=_lib.NOISE_PHILOX, seed=9)
+    for n in (2, 16, 48):
+        b = x[:n].contiguous().clone()
+        eng.sample_loop_(b, xc[:n].contiguous(), 999, 5, noise_mode=_lib.NOISE_PHILOX, seed=9)
+        assert torch.equal(b, a[:n]), n
+
+
 @pytest.mark.parametrize("T", [120, 196, 48])
 def test_outlier_heavy_weights_stay_within_the_bar(prec, T):
     """The synthetic weights follow the reference's initialisation; a trained checkpoint may not.  One scale per row makes
