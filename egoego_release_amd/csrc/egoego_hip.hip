@@ -81,6 +81,8 @@ struct egoego_ctx {
     int D, DP, KE, H, HD, NOUT, S;
     std::vector<void*> allocs;
     __bf16 *w_embed, *w_out;
+    int8_t* w_out_8;  // linear_out as int8 slices [NOUT][512] + row scales (precision 9's product path)
+    float* s_out;
     float *b_embed, *b_out, *pe, *tt_table, *sched;
     std::vector<LayerDev> layers;
     bool have_weights, have_sched;
@@ -493,19 +495,19 @@ static int launch_embed_tt(const EmbedArgs& ea, int rows, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return 0;
 }
-template <int TT>
+template <int TT, bool I8>
 static int launch_out_tt(const OutArgs& oa, int rows, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        HIP_TRY(allow_smem(out_kernel<TT, 1>, TT * 32 * 1024));
-        HIP_TRY(allow_smem(out_kernel<TT, 2>, TT * 32 * 1024));
+        HIP_TRY(allow_smem((out_kernel<TT, 1, I8>), TT * 32 * 1024));
+        HIP_TRY(allow_smem((out_kernel<TT, 2, I8>), TT * 32 * 1024));
         once = true;
     }
     const int nb = rows / (32 * TT);
     if (nb <= 128)  // fewer token blocks than half the CUs: two workgroups per token block, 128 features each
-        out_kernel<TT, 2><<<dim3(2 * nb), dim3(256), TT * 32 * 1024, s>>>(oa);
+        out_kernel<TT, 2, I8><<<dim3(2 * nb), dim3(256), TT * 32 * 1024, s>>>(oa);
     else
-        out_kernel<TT, 1><<<dim3(nb), dim3(256), TT * 32 * 1024, s>>>(oa);
+        out_kernel<TT, 1, I8><<<dim3(nb), dim3(256), TT * 32 * 1024, s>>>(oa);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -607,7 +609,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         const bool attn_geom = g.KT == 4 && g.Lp == BLK_A_T && (i8 || nw * H >= 192);
         const bool fused_attn = attn_geom && !dbg_qkv;
         // the layer's output also as int8 slices: the next layer's projections consume them
-        const bool q8_out = i8 && li + 1 < c->cfg.n_dec_layers;
+        const bool q8_out = i8 && (li + 1 < c->cfg.n_dec_layers || act8_only);  // (precision 9's product path: linear_out reads int8 rows too)
         int8_t* const q8p = q8_out ? w.hA8 : nullptr;
         if (fused_attn && i8) {
             ProfScope ps(c, EGOEGO_K_QKV, s);
@@ -728,10 +730,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 ta.w2 = L.w_2; ta.w2_plane = (size_t)N_MODEL * N_MODEL;
                 ta.ln2 = EpiResLN<2, 4, 0>{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
                 if (act8_only) {
-                    // residuals from the int8 rows; split-bf16 rows only out of the last layer (linear_out's operand)
+                    // residuals from the int8 rows; no split-bf16 rows at all (linear_out reads the last layer's int8 rows)
                     ta.ln1.res8 = w.hA8; ta.ln1.res8_plane = w.h_plane; ta.ln1.res8_scale = w.hA_scale; ta.ln1.out = nullptr;
                     ta.ln2.res8 = w.hB8; ta.ln2.res8_plane = w.h_plane; ta.ln2.res8_scale = w.hB_scale;
-                    if (li + 1 < c->cfg.n_dec_layers) ta.ln2.out = nullptr;
+                    ta.ln2.out = nullptr;
                 }
                 ta.stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
                 EG_DBG(ta.trace = g_trace;)
@@ -840,8 +842,20 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     if (io.run_out) {
         ProfScope ps(c, EGOEGO_K_OUT, s);
         if (NP == 2 && direct_io) {
-            OutArgs oa{w.hA, w.h_plane, c->w_out, (size_t)c->NOUT * N_MODEL, EpiOut<2>{io.out}};
-            if (int r = launch_out_tt<1>(oa, rows, s)) return r;
+            OutArgs oa{w.hA, w.h_plane, c->w_out, (size_t)c->NOUT * N_MODEL, EpiOut<2>{io.out},
+                       w.hA8, w.h_plane, w.hA_scale, c->w_out_8, (size_t)c->NOUT * N_MODEL, c->s_out};
+            if (int r = act8_only ? launch_out_tt<1, true>(oa, rows, s) : launch_out_tt<1, false>(oa, rows, s)) return r;
+        } else if (NP == 2 && act8_only) {
+            // the last layer's output exists as int8 rows only: linear_out on int8 slices, 256 features x 128 tokens per eight-wave workgroup
+            GemmOperands go{(const __bf16*)c->w_out_8, (size_t)c->NOUT * N_MODEL / 2, (const __bf16*)w.hA8, w.h_plane / 2, N_MODEL / 32, 1, rows / 128, row0 / 128 EG_DBG(, 0, nullptr)};
+            auto kern = gemm_i8_kernel<AW8K, EpiOut<2>>;
+            static bool once = false;
+            if (!once) {
+                HIP_TRY(allow_smem(kern, AW8K::SMEM_BYTES));
+                once = true;
+            }
+            kern<<<dim3(go.ntb), dim3(AW8K::NT), AW8K::SMEM_BYTES, s>>>(go, c->s_out, w.hA_scale, EpiOut<2>{io.out});
+            HIP_TRY(hipGetLastError());
         } else {
             GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c EG_DBG(, g_ablate, g_trace)};
             EpiOut<NP> e{io.out};
@@ -1031,6 +1045,10 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
     if ((r = dev_alloc(c, (void**)&c->w_out, (size_t)2 * c->NOUT * N_MODEL * 2, true, s))) return r;
     if ((r = pack_weight(wt->linear_out_w, D, N_MODEL, N_MODEL, 0, c->w_out, (size_t)c->NOUT * N_MODEL, N_MODEL / 16, 0, 0, s))) return r;
     if ((r = copy_vec(c, &c->b_out, wt->linear_out_b, D, c->NOUT, s))) return r;
+    if ((r = dev_alloc(c, (void**)&c->w_out_8, (size_t)2 * c->NOUT * N_MODEL, true, s))) return r;
+    if ((r = dev_alloc(c, (void**)&c->s_out, sizeof(float) * c->NOUT, true, s))) return r;
+    k_pack_rows_i8<<<D, 256, 0, s>>>(wt->linear_out_w, N_MODEL, N_MODEL, c->w_out_8, (size_t)c->NOUT * N_MODEL, c->s_out, 0);
+    HIP_TRY(hipGetLastError());
     c->layers.resize(c->cfg.n_dec_layers);
     for (int li = 0; li < c->cfg.n_dec_layers; ++li) {
         const egoego_layer_weights& lw = wt->layers[li];

@@ -583,17 +583,32 @@ struct OutArgs {
     const __bf16* w;   // [256][512] (rows >= d_feats zero)
     size_t w_plane;
     EpiOut<2> epi;
+    // I8 builds (precision 9's product path: the last layer hands its output over as int8 rows only): the same contraction on int8
+    // slices — the rows with one scale each, linear_out's weights with one scale per output row
+    const int8_t* h8;
+    size_t h8_plane;   // bytes between the slices
+    const float* h_scale;
+    const int8_t* w8;  // [256][512] two slices (rows >= d_feats zero, scale 0)
+    size_t w8_plane;
+    const float* s_w;  // [256]
 };
 // FS = 2: grids of at most 128 token blocks (half the CUs) split the 256 output features over two workgroups per token block
 // (a wave then owns 32 features): the posterior epilogue is elementwise, so nothing crosses the split.
-template <int TT, int FS>
+template <int TT, int FS, bool I8 = false>
 __global__ __launch_bounds__(256, 1) void out_kernel(OutArgs a) {
     constexpr int FT = 2 / FS;
-    using G = DirectGemm<FT, TT, TAIL_RING_IO>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
     const int tb = (int)blockIdx.x / FS, fh = (int)blockIdx.x % FS;
     f32x16 acc[FT][TT];
-    G::run(acc, a.h, a.h_plane, 32, a.w, a.w_plane, smem, tb * TT, wave, lane, [] {}, (fh * 4 + wave) * FT);
+    if constexpr (I8) {
+        using G = DirectGemm<FT, TT, TAIL_RING_IO, false, true>;
+        I8Acc q[FT][TT];
+        G::run(q, (const __bf16*)a.h8, a.h8_plane / 2, 16, (const __bf16*)a.w8, a.w8_plane / 2, smem, tb * TT, wave, lane, [] {}, (fh * 4 + wave) * FT);
+        i8_dequant_tile<false>(q, acc, a.s_w, a.h_scale, (fh * 4 + wave) * FT * 32, tb * 32 * TT, lane);
+    } else {
+        using G = DirectGemm<FT, TT, TAIL_RING_IO>;
+        G::run(acc, a.h, a.h_plane, 32, a.w, a.w_plane, smem, tb * TT, wave, lane, [] {}, (fh * 4 + wave) * FT);
+    }
     a.epi.template run<FT, TT>(acc, (fh * 4 + wave) * FT * 32, tb * 32 * TT, lane, wave, 0, smem);
 }

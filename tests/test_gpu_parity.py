@@ -404,7 +404,8 @@ def test_degenerate_inputs_give_finite_results(prec):
             want = O.denoise(sd, x_all, t)
         got = m.denoise(x_all[..., :198].contiguous().cuda(), t.cuda(), x_all[..., 198:].contiguous().cuda()).cpu()
         assert torch.isfinite(got).all()
-        assert (got - want).abs().max().item() < 3e-4, T
+        err = (got - want).abs().max().item()
+        assert err < (5e-4 if prec == _lib.PREC_I8X3_FC else 3e-4), (T, err)
 
 
 def test_graph_replay_equals_individual_launches(prec):
