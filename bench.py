@@ -251,7 +251,8 @@ def main():
         fl_step = flops_per_window_step(T) * B
         i8 = args.precision in (8, 9) and 64 < T + 1 <= 128
         i8_long = args.precision in (8, 9) and T + 1 > 128   # int8 projections written as int8 images + separate int8 attention core
-        attn_name = "attn_layer_i8w_kernel" if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
+        half_q = i8 and Bl * 4 * 2 <= 128   # the library's dispatch: two half-query workgroups per (window, head) up to 16 windows
+        attn_name = ("attn_layer_i8h_kernel" if half_q else "attn_layer_i8w_kernel") if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
         attn_peak = PEAK_I8_TOPS if (i8 or i8_long) else PEAK_BF16_TFLOPS
         attn_flops = Bl * 2 * (T + 1) * 512 * 3 * 1024 if i8_long else qkv_attn_flops_per_launch(Bl, T)
         attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None
@@ -280,8 +281,12 @@ def main():
         tail_txt = ((" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, two workgroups per CU, LDS-ring operands; "
                      f"fc split-bf16, {ffn_txt}" + (" in two passes into one int32 accumulator)" if args.precision == 8 else ")"))
                     if big_tail else
-                    (" (the same three GEMMs per 32/64 tokens for small batches: weights streamed into registers, activations by LDS-DMA "
-                     f"chunks; fc {'on int8 slices, one integer chain per head' if fc8 else 'split-bf16'}, {ffn_txt})"))
+                    ((" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 32 tokens, all three contractions on int8 slices: weights "
+                      "streamed into registers, the attention output by LDS-DMA chunks with one integer chain per head, the LayerNorm-1 rows "
+                      "and the hidden rows resident in LDS; " + ("two 4-wave workgroups per CU)" if rows_p // 32 > 256 else "one 8-wave workgroup per CU)"))
+                     if fc8 else
+                     (" (the same three GEMMs per 32/64 tokens for small batches: weights streamed into registers, activations by LDS-DMA "
+                      f"chunks; fc split-bf16, {ffn_txt})")))
         # the peak of the MFMAs the kernel issues: all int8 (precision 9), fc bf16 + FFN int8 (precision 8: the two halves of its
         # FLOPs at 2.5 and 5 P, i.e. 3333 T together), all bf16 (precisions 3, 1)
         tail_peak = PEAK_I8_TOPS if fc8 else (2.0 / (1.0 / PEAK_BF16_TFLOPS + 1.0 / PEAK_I8_TOPS) if args.precision == 8 else PEAK_BF16_TFLOPS)
@@ -290,7 +295,9 @@ def main():
             "bound": "mfma", "kernel": tail_name + tail_txt,
             "achieved": tail_ach, "peak": tail_peak, "unit": tail_unit, "frac": (tail_ach / tail_peak) if tail_ach else None,
             "traffic": (traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
-            "algorithmic_bytes": 4 * Bl * L * (1024 + 512 + 512) + 4.2e6,
+            # precision 9: the attention output (1024 x 2 B), the residual rows in and the layer's rows out (512 x 2 B each) per token
+            # + the int8 weights once; the other precisions: split-bf16 rows (4 B per value) incl. the hidden activations
+            "algorithmic_bytes": (2 * Bl * L * (1024 + 512 + 512) + 2.1e6) if fc8 else (4 * Bl * L * (1024 + 512 + 512) + 4.2e6),
             "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * ms_step) if t_n else None,
             "note": "measured like the attention-layer kernel; 3 MFMAs are issued per product (split-bf16: K=16 per MFMA; int8 slices: K=32 per "
                     "MFMA at the same issue time); normalised by the peak of the MFMAs the kernel actually issues"}
@@ -307,7 +314,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": {8: "i8x3 + bf16x3 (attention layer and FFN: 2 x int8 slices per operand, int32 accumulate; embed, fc, linear_out: split-bf16, fp32 accumulate)",
-                      9: "i8x3 + bf16x3 (attention layer, fc and FFN: 2 x int8 slices per operand, int32 accumulate; embed, linear_out: split-bf16)",
+                      9: "i8x3 + bf16x3 (attention layer, fc, FFN and linear_out: 2 x int8 slices per operand, int32 accumulate; embed: split-bf16, fp32 accumulate)",
                       3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)", 1: "bf16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: B={B} windows x T={T} frames x 198 feats split over {world} GPU(s) "
