@@ -12,9 +12,14 @@ PEAK_TF, PEAK_I8, PEAK_HBM = 2500.0, 5000.0, 8.0  # TFLOP/s bf16 dense, TOP/s in
 ALG = {  # kernel tag -> (what, algorithmic FLOPs per launch, algorithmic HBM bytes per launch)
     "attn_layer_i8": ("Q/K/V projections + softmax + PV (one layer), int8 slices", B * (2 * L * DM * 3 * HD + 4 * L * L * HD),
                              2 * B * L * DM + 4 * B * L * HD + 3.2e6),
-    "tail_kernel|layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; precision 9: all three contractions on int8 slices, int8 peak)", B * L * (2 * HD * DM + 4 * DM * DM), 4 * B * L * (HD + DM + DM) + 4.2e6),
-    "EpiEmbed": ("embed GEMM + time token + pos-emb", 2 * B * T * 2 * D * DM, 4 * B * T * 2 * D + 4 * B * L * DM),
-    "EpiOut": ("linear_out + DDPM posterior", 2 * B * T * DM * D, 4 * B * L * DM + 3 * 4 * B * T * D),
+    # precision 9: the attention output (2 B x 1024), the residual rows in and the layer's rows out (2 B x 512 each) per token; the
+    # LayerNorm-1 rows and the hidden rows stay in LDS
+    "tail_kernel|layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; precision 9: all three contractions on int8 slices, FFN operands resident in LDS; int8 peak)",
+                               B * L * (2 * HD * DM + 4 * DM * DM), 2 * B * L * (HD + DM + DM) + 2.1e6),
+    # the split-bf16 operand (x | x_cond, 4 B per value) in, int8 rows (2 B per value) out
+    "EpiEmbed": ("embed GEMM + time token + pos-emb (split-bf16 in, int8 rows out)", 2 * B * T * 2 * D * DM, 4 * B * T * 2 * D + 2 * B * L * DM),
+    # int8 rows in; x read + written (fp32), the next step's embed operand written (split-bf16)
+    "EpiOut": ("linear_out on int8 slices + DDPM posterior", 2 * B * T * DM * D, 2 * B * L * DM + 3 * 4 * B * T * D),
 }
 
 
@@ -29,10 +34,10 @@ def main():
         us = float(st["AverageNs"]) / 1e3
         tr = next((v for k, v in traffic.items() if any(t in k for t in tags)), None)
         hbm = tr["hbm_bytes_per_launch"] if tr else None
-        peak = PEAK_I8 if ("i8" in tag or "tail_kernel" in tag) else PEAK_TF  # (precision 9: the tail issues int8 MFMAs only)
+        peak = PEAK_I8 if ("i8" in tag or "tail_kernel" in tag or "gemm_i8" in st["Name"]) else PEAK_TF  # (precision 9: the tail and linear_out issue int8 MFMAs only)
         rows.append((tags[0], what, us, float(st["Percentage"]), flops / us / 1e6, flops / us / 1e6 / peak, 3 * flops / us / 1e6 / peak,
                      abytes / 1e6, (hbm or 0) / 1e6, (hbm or 0) / us / 1e6))
-    out = [f"# Per-kernel roofline, round {int(rnd[1:])} (B=256, T=120, precision i8x3: int8-slice attention layer and FFN + split-bf16 elsewhere; from the files in this directory)", "",
+    out = [f"# Per-kernel roofline, round {int(rnd[1:])} (B=256, T=120, precision {9 if int(rnd[1:]) >= 3 else 8}: int8-slice attention layer{', fc, FFN and linear_out; split-bf16 embed' if int(rnd[1:]) >= 3 else ' and split-bf16 elsewhere'}; from the files in this directory)", "",
            "MFMA bound: 2.5 PFLOP/s dense bf16, 5 POP/s dense int8; both split-bf16 and the int8 slices issue 3 MFMAs per algorithmic product, so the algorithmic fraction is capped at 33 %.",
            "HBM bound: 8 TB/s.  `traffic` = (2·FETCH_SIZE + WRITE_SIZE)·1024 from the PMC passes.", "",
            "| kernel | what | avg µs | % of GPU time | algorithmic TFLOP/s (TOP/s) | frac of the dtype's peak | MFMA-pipe frac (×3) | algorithmic MB | measured HBM MB | HBM TB/s |",
