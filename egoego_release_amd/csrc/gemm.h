@@ -398,26 +398,6 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_kernel(GemmOperands g, Ep
     GemmBody<C, Epi>::run(g, epi, fblk, tblk + g.tblk0, smem);
 }
 
-// The same over int8-slice operands (one scale per weight row, one per activation row): integer main loop, dequantised tile, fp32 epilogue.
-template <class C, class Epi>
-__global__ __launch_bounds__(C::NT, C::MINW) void gemm_i8_kernel(GemmOperands g, const float* sw, const float* sa, Epi epi) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    int fblk, tblk;
-    grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
-    tblk += g.tblk0;
-    const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
-    const int wf = wave % C::NWF, wt = wave / C::NWF;
-    const int f0 = (fblk * C::WT + wf * C::FT) * 32, t0 = (tblk * C::AT + wt * C::TT) * 32;
-    f32x16 acc[C::FT][C::TT];
-    {
-        I8Acc q[C::FT][C::TT];
-        GemmBody<C, Epi>::mainloop(g, fblk, tblk, smem, q);
-        i8_dequant_tile<true>(q, acc, sw, sa, f0, t0, lane);
-    }
-    epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
-}
-
 // Q/K feature blocks run swapped, V feature blocks un-swapped; the branch is block-uniform.
 template <class CQK, class EpiQK, class CV, class EpiV>
 __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_kernel(GemmOperands g, EpiQK eqk, EpiV ev, int n_qk_fblocks) {
@@ -489,6 +469,26 @@ EG_D void i8_dequant_tile(const QT (&q)[FT][TT], f32x16 (&acc)[FT][TT], const fl
         __builtin_amdgcn_sched_barrier(0);  // ... and the epilogue's loads from moving up beside the still-live integer sums
     }
 }
+// The same over int8-slice operands (one scale per weight row, one per activation row): integer main loop, dequantised tile, fp32 epilogue.
+template <class C, class Epi>
+__global__ __launch_bounds__(C::NT, C::MINW) void gemm_i8_kernel(GemmOperands g, const float* sw, const float* sa, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int fblk, tblk;
+    grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
+    tblk += g.tblk0;
+    const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
+    const int wf = wave % C::NWF, wt = wave / C::NWF;
+    const int f0 = (fblk * C::WT + wf * C::FT) * 32, t0 = (tblk * C::AT + wt * C::TT) * 32;
+    f32x16 acc[C::FT][C::TT];
+    {
+        I8Acc q[C::FT][C::TT];
+        GemmBody<C, Epi>::mainloop(g, fblk, tblk, smem, q);
+        i8_dequant_tile<true>(q, acc, sw, sa, f0, t0, lane);
+    }
+    epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
+}
+
 // un-swapped accumulator (lane owns a feature, registers walk tokens)
 EG_D void i8_dequant_rows(const I8Acc& q, f32x16& o, float sw, const float* sa8) {
     const float sw256 = sw * 256.0f;

@@ -49,6 +49,13 @@ for i in range(1, 7):
 for nm, (pro, st, en) in {"fc": (0, 7, 1), "FFN-1": (2, 8, 3), "FFN-2": (4, 9, 5)}.items():
     print(f"{nm:6s} prologue (first chunk + weights + residual in flight -> landed) {((tr[:, st] - tr[:, pro]) / 100.0).mean():6.2f} us,"
           f" chunk loop {((tr[:, en] - tr[:, st]) / 100.0).mean():6.2f} us at {((tr[:, 16 + en] - tr[:, 16 + st]) / ((tr[:, en] - tr[:, st]) / 100.0)).mean():5.0f} MHz")
+start = (tr[:, 0] - t0) / 100.0
+early = start < 5.0  # the workgroups resident from the launch on; the others start as these finish
+for nm, sel in (("first round (start < 5 us)", early), ("later rounds", ~early)):
+    if sel.any():
+        print(f"{nm:28s} n={int(sel.sum()):4d}  fc prologue {((tr[sel, 7] - tr[sel, 0]) / 100.0).mean():6.2f} us  fc loop {((tr[sel, 1] - tr[sel, 7]) / 100.0).mean():6.2f}"
+              f"  LN-1 {((tr[sel, 2] - tr[sel, 1]) / 100.0).mean():5.2f}  FFN-1 {((tr[sel, 4] - tr[sel, 2]) / 100.0).mean():5.2f}  FFN-2+LN-2 {((tr[sel, 6] - tr[sel, 4]) / 100.0).mean():5.2f}"
+              f"  total {((tr[sel, 6] - tr[sel, 0]) / 100.0).mean():6.2f}")
 tot = (tr[:, 6] - tr[:, 0]) / 100.0
 print(f"workgroup total     mean {tot.mean():7.2f} us   min {tot.min():7.2f}   max {tot.max():7.2f}")
 print(f"kernel span {(tr[:, 6].max() - t0) / 100.0:.2f} us; start spread {(tr[:, 0].max() - t0) / 100.0:.2f} us")
