@@ -8,7 +8,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from egoego_release_amd import ModelConfig, make_weights
+from egoego_release_amd import ModelConfig, make_weights, _lib
+if "EGOEGO_PERFDEBUG_TAG" in os.environ:  # check a variant build (libegoego_hip_perfdebug_<tag>.so)
+    _lib.use_perfdebug_build()
 from egoego_release_amd.model import CondGaussianDiffusion
 
 cfg = ModelConfig(max_timesteps=121)
