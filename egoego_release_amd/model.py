@@ -14,6 +14,7 @@ The plain-PyTorch `forward` of the parameter containers exists solely for the tr
 (`p_losses` / `forward`), which is outside the accelerated path.
 """
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -280,7 +281,27 @@ class CondGaussianDiffusion(nn.Module):
                                           0 if self.hip_graph else _lib.FLAG_NO_GRAPH)
             self._slot.key = key
             self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
+            self._warn_if_outlier_heavy()
         return self._slot.engine
+
+    def _warn_if_outlier_heavy(self):
+        """The int8-slice precisions keep one scale per row (16-bit fixed point): a few LayerNorm gains an order of magnitude
+        above the rest cost every other feature of a row that many bits.  Measured (tools/hostile_weights_check.py): 8x gains on
+        six features stay inside the 1e-3 bar in every precision, 25x gains leave it in precision 9 (1.4e-3) and come close in
+        precision 8 (5.5e-4).  Checked once per weight (re)pack; a warning, not a fallback — the caller picks the precision."""
+        if self.hip_precision not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
+            return
+        worst = 0.0
+        for name, p in self.denoise_fn.named_parameters():
+            if name.endswith("layer_norm.weight") and p.numel() > 1:
+                a = p.detach().abs().float()
+                worst = max(worst, float(a.max() / a.median().clamp_min(1e-12)))
+        limit = 10.0 if self.hip_precision == _lib.PREC_I8X3_FC else 20.0
+        if worst > limit:
+            warnings.warn(
+                f"LayerNorm gains span a factor of {worst:.0f} (max / median): hip_precision={self.hip_precision} keeps one int8-slice "
+                f"scale per row and may leave the 1e-3 bar on such a checkpoint; compare with tools/precision_compare.py or set "
+                f"model.hip_precision = {_lib.PREC_I8X3 if self.hip_precision == _lib.PREC_I8X3_FC else _lib.PREC_BF16X3}", RuntimeWarning, stacklevel=3)
 
     def _check_t(self, t):
         """The reference indexes its schedule buffers with t (`extract`, M:36-39) and the time embedding accepts any

@@ -408,6 +408,33 @@ def test_degenerate_inputs_give_finite_results(prec):
         assert err < (5e-4 if prec == _lib.PREC_I8X3_FC else 3e-4), (T, err)
 
 
+def test_outlier_heavy_layernorm_gains_raise_a_warning():
+    """One scale per row is 16-bit fixed point: LayerNorm gains far above the rest cost the other features their bits
+    (DESIGN.md 3c).  The module says so when such a checkpoint is packed for an int8-slice precision — and only then."""
+    import warnings
+    cfg = ModelConfig(max_timesteps=121)
+    sd = make_weights(cfg, 0)
+    x = torch.zeros(1, 120, 198, device="cuda")
+    t = torch.zeros(1, dtype=torch.long, device="cuda")
+    def build(state, prec):
+        m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+        m.load_state_dict(state, strict=False)
+        m.hip_precision = prec
+        return m.cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the reference's initialisation: no warning in any precision
+        for prec in (_lib.PREC_I8X3_FC, _lib.PREC_I8X3, _lib.PREC_BF16X3):
+            build(sd, prec).denoise(x, t, x)
+    hot = {k: v.clone() for k, v in sd.items()}
+    k0 = next(k for k in hot if k.endswith("layer_norm.weight"))
+    hot[k0][:6] *= 25.0
+    with pytest.warns(RuntimeWarning, match="LayerNorm gains span"):
+        build(hot, _lib.PREC_I8X3_FC).denoise(x, t, x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        build(hot, _lib.PREC_BF16X3).denoise(x, t, x)
+
+
 def test_graph_replay_equals_individual_launches(prec):
     """egoego_sample_loop captures one step into a hipGraph and replays it (timestep and step index live in device
     memory); the result must be bit-identical to launching every kernel of every step, for Philox and for injected
