@@ -1,5 +1,6 @@
-// attn_layer_i8h.h — the eight-wave attention layer (attn_layer_i8w.h, TM:71-88) for grids of at most a QUARTER of the CUs: up to 16
-// windows x 4 heads per call — the reference's own sample_bs = 1 (BASELINE configs[0]), small interactive batches.
+// attn_layer_i8h.h — the eight-wave attention layer (attn_layer_i8w.h, TM:71-88) for small grids: up to 24 windows x 4 heads per
+// call (its 192 workgroups then fill three quarters of the CUs) — the reference's own sample_bs = 1 (BASELINE configs[0]), small
+// interactive batches.
 //
 // A (window, head) workgroup is a serial chain of ~38 us whatever the batch, and with 64 of them three quarters of the chip idle.
 // Here TWO workgroups share a (window, head): each projects K and V for ALL keys (redundantly — that work cannot be split without an

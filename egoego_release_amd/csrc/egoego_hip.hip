@@ -437,11 +437,11 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return 0;
 }
-// two half-query workgroups per (window, head) while they fill at most HALF the CUs (measured, ms per step at B = 1 / 16 / 32:
-// 0.269 / 0.268 / 0.303 with them, 0.292 / 0.295 / 0.297 without: with every CU busy the redundant K / V projections cost more than
-// the shorter chain saves)
+// two half-query workgroups per (window, head) while they fill at most three quarters of the CUs (measured, ms per step at
+// B = 1 / 16 / 20 / 24 / 32: 0.269 / 0.268 / 0.272 / 0.287 / 0.303 with them, 0.292 / 0.295 / 0.294 / 0.296 / 0.297 without: with every CU
+// busy the redundant K / V projections cost more than the shorter chain saves)
 #ifndef ATTN_HALF_MAX_BLOCKS
-#define ATTN_HALF_MAX_BLOCKS 128
+#define ATTN_HALF_MAX_BLOCKS 192
 #endif
 #ifndef TAIL8_MAX_BLOCKS
 #define TAIL8_MAX_BLOCKS 256
@@ -624,7 +624,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
                 once = true;
             }
-            // a quarter of the CUs' worth of (window, head) pairs or fewer: two workgroups per pair, half the queries each (attn_layer_i8h.h)
+            // up to 24 windows x 4 heads: two workgroups per (window, head), half the queries each (attn_layer_i8h.h)
             if (nw * H * 2 <= ATTN_HALF_MAX_BLOCKS)
                 attn_layer_i8h_kernel<<<dim3(nw * H * 2), dim3(512), AL_SMEM_BYTES, s>>>(al);
             else
