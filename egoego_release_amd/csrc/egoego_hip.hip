@@ -443,6 +443,9 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
 #ifndef ATTN_HALF_MAX_BLOCKS
 #define ATTN_HALF_MAX_BLOCKS 192
 #endif
+#ifndef EMBED8_MAX_BLOCKS
+#define EMBED8_MAX_BLOCKS 256
+#endif
 #ifndef TAIL8_MAX_BLOCKS
 #define TAIL8_MAX_BLOCKS 256
 #endif
@@ -488,10 +491,14 @@ template <int TT>
 static int launch_embed_tt(const EmbedArgs& ea, int rows, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        HIP_TRY(allow_smem(embed_kernel<TT>, TT * 32 * 1024));
+        HIP_TRY(allow_smem((embed_kernel<TT, 4>), TT * 32 * 1024));
+        HIP_TRY(allow_smem((embed_kernel<TT, 8>), TT * 32 * 1024));
         once = true;
     }
-    embed_kernel<TT><<<dim3(rows / (32 * TT)), dim3(256), TT * 32 * 1024, s>>>(ea);
+    if (rows / (32 * TT) <= EMBED8_MAX_BLOCKS)  // at most one workgroup per CU: eight waves
+        embed_kernel<TT, 8><<<dim3(rows / (32 * TT)), dim3(512), TT * 32 * 1024, s>>>(ea);
+    else
+        embed_kernel<TT, 4><<<dim3(rows / (32 * TT)), dim3(256), TT * 32 * 1024, s>>>(ea);
     HIP_TRY(hipGetLastError());
     return 0;
 }

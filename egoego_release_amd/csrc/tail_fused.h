@@ -565,16 +565,18 @@ struct EmbedArgs {
     size_t w_plane;
     EpiEmbed<2, 4, 0> epi;
 };
-template <int TT>
-__global__ __launch_bounds__(256, 1) void embed_kernel(EmbedArgs a) {
-    using G = DirectGemm<4, TT, TAIL_RING_IO, true>;  // the embed operand has 26 k-blocks (2 x 208 columns)
+// NWV = 8: eight 256-register waves, 64 features each (like the eight-wave tail: for grids of at most one workgroup per CU)
+template <int TT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, (NWV == 8 ? 2 : 1)) void embed_kernel(EmbedArgs a) {
+    constexpr int FT = 16 / NWV;
+    using G = DirectGemm<FT, TT, TAIL_RING_IO, true, false, NWV>;  // the embed operand has 26 k-blocks (2 x 208 columns)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id_uniform(), lane = threadIdx.x & 63;
-    f32x16 acc[4][TT];
+    f32x16 acc[FT][TT];
     G::run(acc, a.x, a.x_plane, a.K16, a.w, a.w_plane, smem, (int)blockIdx.x * TT, wave, lane, [] {});
-    const EpiEmbed<2, 4, 32 * TT> e{a.epi.bias, a.epi.pe, a.epi.tt_table, a.epi.t_idx, a.epi.out, a.epi.out_plane, a.epi.Lp, a.epi.T, a.epi.B,
-                                    a.epi.q8, a.epi.q8_plane, a.epi.q8_scale, a.epi.state, a.epi.ts};
-    e.template run<4, TT>(acc, wave * 128, (int)blockIdx.x * 32 * TT, lane, wave, 0, smem);
+    const EpiEmbed<2, NWV, 32 * TT> e{a.epi.bias, a.epi.pe, a.epi.tt_table, a.epi.t_idx, a.epi.out, a.epi.out_plane, a.epi.Lp, a.epi.T, a.epi.B,
+                                      a.epi.q8, a.epi.q8_plane, a.epi.q8_scale, a.epi.state, a.epi.ts};
+    e.template run<FT, TT>(acc, wave * FT * 32, (int)blockIdx.x * 32 * TT, lane, wave, 0, smem);
 }
 
 struct OutArgs {
