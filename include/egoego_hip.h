@@ -58,9 +58,12 @@ enum { EGOEGO_NOISE_INJECTED = 0, EGOEGO_NOISE_PHILOX = 1, EGOEGO_NOISE_NONE = 2
  * 8 = the contractions whose input rows have one natural scale — the Q/K/V projections, QK^T, PV and the two FFN convs —
  * computed from two int8 slices per operand (three int8 MFMAs per product, int32 accumulate; same parity bar); embed, fc and
  * linear_out stay split-bf16.
- * 9 = 8 with the attention output projection (fc) on int8 slices as well: the attention kernels hand O over as int8 rows with
- * one scale per row and head, fc runs one exact integer chain per head.  Same parity bar, about twice the error of 8
- * (~2.5e-4 against ~1.3e-4 on one forward); faster below ~128 windows per GPU, slightly slower above. */
+ * 9 = 8 with the attention output projection (fc) and linear_out on int8 slices as well: the attention kernels hand O over as
+ * int8 rows with one scale per row and head, fc runs one exact integer chain per head, and every activation that crosses memory
+ * between the kernels of a step is an int8 row (the residual stream included).  Same parity bar, about twice the error of 8
+ * (~3e-4 against ~1.3e-4 on one forward), about 30 % less time per step at every batch size (8: +40 %, 3: +80-90 % over 9),
+ * and more sensitive to outlier-heavy checkpoints
+ * (LayerNorm gains far above the rest: DESIGN.md 3c). */
 enum { EGOEGO_PREC_BF16X3 = 3, EGOEGO_PREC_BF16X1 = 1, EGOEGO_PREC_I8X3 = 8, EGOEGO_PREC_I8X3_FC = 9 };
 
 typedef struct egoego_ctx egoego_ctx;
