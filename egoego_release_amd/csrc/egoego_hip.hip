@@ -15,6 +15,7 @@
 #include "attn_layer_i8.h"
 #include "attn_layer_i8w.h"
 #include "attn_layer_i8h.h"
+#include "attn_split_i8.h"
 #include "attn_core_i8.h"
 #include "common.h"
 #include "gemm.h"
@@ -440,6 +441,13 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
 // two half-query workgroups per (window, head) while they fill at most three quarters of the CUs (measured, ms per step at
 // B = 1 / 16 / 20 / 24 / 32: 0.269 / 0.268 / 0.272 / 0.287 / 0.303 with them, 0.292 / 0.295 / 0.294 / 0.296 / 0.297 without: with every CU
 // busy the redundant K / V projections cost more than the shorter chain saves)
+// the projections as three workgroups per (window, head) + a core launch (attn_split_i8.h) while those fit the chip at once
+// (measured, ms per step at B = 1 / 8 / 12 / 16 / 20 / 21: 0.232 / 0.235 / 0.237 / 0.247 / 0.265 / 0.273 against the half-query
+// kernel's 0.266 / 0.265 / 0.265 / 0.266 / 0.270 / 0.273; in two rounds — B = 24 / 32 / 40 — it loses: 0.304 / 0.333 / 0.358 against
+// 0.283 / 0.297 / 0.312)
+#ifndef ATTN_SPLIT_MAX_BLOCKS
+#define ATTN_SPLIT_MAX_BLOCKS 256
+#endif
 #ifndef ATTN_HALF_MAX_BLOCKS
 #define ATTN_HALF_MAX_BLOCKS 192
 #endif
@@ -629,8 +637,18 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             if (!once) {
                 HIP_TRY(allow_smem(attn_layer_i8w_kernel, AL_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
+                HIP_TRY(allow_smem(attn_proj_i8_kernel, ATTN_PROJ_SMEM));
+                HIP_TRY(allow_smem(attn_core_s_kernel, ATTN_CORE_S_SMEM));
                 once = true;
             }
+            // the projections as three workgroups per (window, head) + a core launch while they fit the chip at once (attn_split_i8.h);
+            // the images go through the Q / K buffers (carved back to back: 256 KiB per window x head), V's column scales through V's
+            if (nw * H * 3 <= ATTN_SPLIT_MAX_BLOCKS) {
+                const AttnSplitBufs sb{(int8_t*)w.Q, w.sq8, w.sk8, (float*)w.V};
+                attn_proj_i8_kernel<<<dim3(nw * H * 3), dim3(512), ATTN_PROJ_SMEM, s>>>(al, sb);
+                HIP_TRY(hipGetLastError());
+                attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
+            } else
             // up to 24 windows x 4 heads: two workgroups per (window, head), half the queries each (attn_layer_i8h.h)
             if (nw * H * 2 <= ATTN_HALF_MAX_BLOCKS)
                 attn_layer_i8h_kernel<<<dim3(nw * H * 2), dim3(512), AL_SMEM_BYTES, s>>>(al);
