@@ -253,7 +253,7 @@ def main():
         i8_long = args.precision in (8, 9) and T + 1 > 128   # int8 projections written as int8 images + separate int8 attention core
         half_q = i8 and Bl * 4 * 2 <= 192   # the library's dispatch: two half-query workgroups per (window, head) up to 24 windows
         split3 = i8 and Bl * 4 * 3 <= 256  # ... and below that the projections as three workgroups per (window, head) + a core launch
-        attn_name = ("attn_proj_i8_kernel" if split3 else "attn_layer_i8h_kernel" if half_q else "attn_layer_i8w_kernel") if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
+        attn_name = ("attn_proj6_i8_kernel" if (i8 and Bl * 4 * 6 <= 256) else "attn_proj_i8_kernel" if split3 else "attn_layer_i8h_kernel" if half_q else "attn_layer_i8w_kernel") if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
         attn_peak = PEAK_I8_TOPS if (i8 or i8_long) else PEAK_BF16_TFLOPS
         attn_flops = Bl * 2 * (T + 1) * 512 * 3 * 1024 if i8_long else qkv_attn_flops_per_launch(Bl, T)
         attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None

@@ -141,6 +141,132 @@ __global__ __launch_bounds__(512, 2) void attn_proj_i8_kernel(AttnLayerArgs a, A
 }
 static constexpr int ATTN_PROJ_SMEM = 8192 + AW8K::SMEM_BYTES;
 
+// The same projections in SIX four-wave workgroups per (window, head): Q and K by token halves (their scales are per token row),
+// V by feature halves (its scales are per feature column over the window's keys) — for calls of at most 10 windows, where each of
+// the six still gets a CU of its own and the projection time halves once more (B=1: 0.232 -> 0.222 ms per step).  256 registers per
+// wave, 68 KiB of LDS.  Per wave the same 64f x 64t tile and the same integer sums; the same epilogue code per value; same images.
+// (Two per CU in more than one round — 22 windows and more — it loses to the one-kernel forms: measured, egoego_hip.hip.)
+using AP6K = GemmCfg<2, 2, 4, 1, 1, 2, false, 2, 3>;  // 256 features x 64 tokens (Q / K half)
+using AP6V = GemmCfg<2, 2, 2, 2, 1, 2, true, 2, 3>;   // 128 features x 128 tokens (V half), un-swapped accumulator
+static constexpr int ATTN_PROJ6_SMEM = 8192 + (AP6K::SMEM_BYTES > AP6V::SMEM_BYTES ? AP6K::SMEM_BYTES : AP6V::SMEM_BYTES);
+
+__global__ __launch_bounds__(256, 2) void attn_proj6_i8_kernel(AttnLayerArgs a, AttnSplitBufs o) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;                     // [256] cross-wave maxima
+    float* p_ws = red + 512;                       // [256] weight row scales of this projection
+    float* p_b = p_ws + 256;                       // [256] biases
+    float* p_hs = p_b + 256;                       // [128] row scales of the window's int8 input rows
+    char* ring = smem + 8192;
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the six workgroups of all H heads of a window share an XCD
+    const int bhl = lid / 6, part = lid - bhl * 6;               // 0, 1: Q token halves; 2, 3: K token halves; 4, 5: V feature halves
+    const int which = part >> 1, half = part & 1;
+    const int bh = bhl + a.bh0;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
+    {
+        const int src = which * a.H * 256 + h * 256 + threadIdx.x;
+        p_ws[threadIdx.x] = a.w_scale[src];
+        p_b[threadIdx.x] = a.bias[src];
+        if (threadIdx.x < 128) p_hs[threadIdx.x] = a.h_scale[b * 128 + threadIdx.x];
+    }  // visible after the first barrier of the main loop
+    int8_t* const img = o.img + ((size_t)bh * 3 + which) * 65536;
+    if (which < 2) {
+        // ---- one token half of Q_h / K_h: four waves side by side along the features
+        const int wf = wave, t0 = half * 64;
+        I8Acc q[2][2];
+        GemmBody<AP6K, NoEpi>::mainloop(g, which * a.H + h, b * 2 + half, ring, q);
+        const float qs = which == 0 ? a.qscale : 1.0f;
+        float* const scales = (which == 0 ? o.sq : o.sk) + (size_t)bh * 128;
+        const int f0 = wf * 64;
+        f32x16 v[2][2];
+        float amax[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float sa = p_hs[t0 + j * 32 + col];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                i8_dequant(q[i][j], v[i][j], p_ws + f0 + i * 32 + 4 * hf, sa);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 b4 = *(const float4*)(p_b + f0 + i * 32 + 8 * gq + 4 * hf);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        v[i][j][4 * gq + c] = (v[i][j][4 * gq + c] + bb[c]) * qs;
+                        amax[j] = fmaxf(amax[j], fabsf(v[i][j][4 * gq + c]));
+                    }
+                }
+            }
+            amax[j] = fmaxf(amax[j], __shfl_xor(amax[j], 32));
+            if (hf == 0) red[wf * 64 + j * 32 + col] = amax[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tl = j * 32 + col, tok = t0 + tl;
+            const float rmax = fmaxf(fmaxf(red[tl], red[64 + tl]), fmaxf(red[128 + tl], red[192 + tl]));
+            const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+            if (wf == 0 && hf == 0) scales[tok] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
+                u32x4 s1, s2;
+                quant16(t, inv, s1, s2);
+                int8_t* dst = img + (((half * 2 + j) * 8 + wf * 2 + i) << 10) + lane * 16;
+                *(u32x4*)dst = s1;
+                *(u32x4*)(dst + AL_SLICE) = s2;
+            }
+        }
+    } else {
+        // ---- one feature half of V_h: waves 2 (features) x 2 (tokens)
+        const int wf = wave & 1, wt = wave >> 1, t0 = wt * 64;
+        I8Acc q[2][2];
+        GemmBody<AP6V, NoEpi>::mainloop(g, (2 * a.H + h) * 2 + half, b, ring, q);
+        const int f0 = half * 128 + wf * 64;  // feature of the head
+        f32x16 v[2][2];
+        float amax[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float sw = p_ws[f0 + i * 32 + col], bf = p_b[f0 + i * 32 + col];
+            amax[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                i8_dequant_rows(q[i][j], v[i][j], sw, p_hs + t0 + j * 32 + 4 * hf);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[i][j][r] += bf;
+                    amax[i] = fmaxf(amax[i], fabsf(v[i][j][r]));
+                }
+            }
+            amax[i] = fmaxf(amax[i], __shfl_xor(amax[i], 32));
+            if (hf == 0) red[wt * 128 + wf * 64 + i * 32 + col] = amax[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int dl = wf * 64 + i * 32 + col, dv = half * 128 + dl;
+            const float cmax = fmaxf(red[dl], red[128 + dl]);
+            const float inv = cmax > 0.f ? I8_QMAX / cmax : 0.f;
+            if (wt == 0 && hf == 0) o.sv[(size_t)bh * 256 + dv] = cmax > 0.f ? cmax / I8_QMAX : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
+                u32x4 s1, s2;
+                quant16(t, inv, s1, s2);
+                int8_t* dst = img + ((((half * 2 + wf) * 2 + i) * 4 + wt * 2 + j) << 10) + lane * 16;
+                *(u32x4*)dst = s1;
+                *(u32x4*)(dst + AL_SLICE) = s2;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void attn_core_s_kernel(AttnLayerArgs a, AttnSplitBufs o) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kv = smem;                               // K image, later V^T image

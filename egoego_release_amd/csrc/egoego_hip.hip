@@ -448,6 +448,13 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
 #ifndef ATTN_SPLIT_MAX_BLOCKS
 #define ATTN_SPLIT_MAX_BLOCKS 256
 #endif
+// ... and as SIX four-wave workgroups per (window, head) while each has a CU of its own (up to 10 windows; measured at B = 1 / 8 /
+// 16 / 20: 0.222 / 0.225 / 0.256 / 0.266 ms against the three-workgroup form's 0.232 / 0.235 / 0.247 / 0.265; at 22 windows and
+// more, two per CU in 1.5+ rounds, it loses to the one-kernel forms: 0.285 / 0.312 / 0.350 against 0.270 / 0.297 / 0.309 at
+// B = 22 / 32 / 40)
+#ifndef ATTN_SPLIT6_MAX_BLOCKS
+#define ATTN_SPLIT6_MAX_BLOCKS 256
+#endif
 #ifndef ATTN_HALF_MAX_BLOCKS
 #define ATTN_HALF_MAX_BLOCKS 192
 #endif
@@ -639,11 +646,17 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_proj_i8_kernel, ATTN_PROJ_SMEM));
                 HIP_TRY(allow_smem(attn_core_s_kernel, ATTN_CORE_S_SMEM));
+                HIP_TRY(allow_smem(attn_proj6_i8_kernel, ATTN_PROJ6_SMEM));
                 once = true;
             }
             // the projections as three workgroups per (window, head) + a core launch while they fit the chip at once (attn_split_i8.h);
             // the images go through the Q / K buffers (carved back to back: 256 KiB per window x head), V's column scales through V's
-            if (nw * H * 3 <= ATTN_SPLIT_MAX_BLOCKS) {
+            if (nw * H * 6 <= ATTN_SPLIT6_MAX_BLOCKS) {  // ... six four-wave workgroups while each of those still gets a CU of its own
+                const AttnSplitBufs sb{(int8_t*)w.Q, w.sq8, w.sk8, (float*)w.V};
+                attn_proj6_i8_kernel<<<dim3(nw * H * 6), dim3(256), ATTN_PROJ6_SMEM, s>>>(al, sb);
+                HIP_TRY(hipGetLastError());
+                attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
+            } else if (nw * H * 3 <= ATTN_SPLIT_MAX_BLOCKS) {
                 const AttnSplitBufs sb{(int8_t*)w.Q, w.sq8, w.sk8, (float*)w.V};
                 attn_proj_i8_kernel<<<dim3(nw * H * 3), dim3(512), ATTN_PROJ_SMEM, s>>>(al, sb);
                 HIP_TRY(hipGetLastError());

@@ -328,8 +328,8 @@ def test_batch_size_invariance_covers_large_batch_kernels(prec):
 
 
 def test_small_grid_kernels_give_the_bits_of_the_large_grid_ones():
-    """Default precision: which kernels run depends on the batch — up to 21 windows the attention projections as three workgroups
-    per (window, head) and a core launch, up to 24 windows two half-query attention workgroups per (window, head), and the eight-wave tail, up to 64 windows the full attention workgroup and the eight-wave tail, beyond that
+    """Default precision: which kernels run depends on the batch — up to 10 windows the attention projections as six workgroups per
+    (window, head) and a core launch, up to 21 windows as three, up to 24 windows two half-query attention workgroups per (window, head), and the eight-wave tail, up to 64 windows the full attention workgroup and the eight-wave tail, beyond that
     the two-workgroups-per-CU tail, embed / linear_out on the direct-operand kernels up to 128 windows — and all of them must
     produce the SAME bits for a window (integer contractions; one summation order for the LayerNorm and softmax row sums)."""
     cfg, sd, m = _model(precision=_lib.PREC_I8X3_FC)
@@ -340,7 +340,7 @@ def test_small_grid_kernels_give_the_bits_of_the_large_grid_ones():
     xc = torch.randn(B, 120, 198, generator=g).cuda()
     t = torch.randint(0, 1000, (B,), generator=g).cuda()
     big = m.denoise(x, t, xc)
-    for n in (1, 3, 16, 21, 22, 24, 25, 64, 100):
+    for n in (1, 3, 10, 11, 16, 21, 22, 24, 25, 64, 100):
         small = m.denoise(x[:n].contiguous(), t[:n].contiguous(), xc[:n].contiguous())
         assert torch.equal(small, big[:n]), n
     a = x.clone()
