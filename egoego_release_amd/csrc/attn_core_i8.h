@@ -61,6 +61,15 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
     const int which = fblk * 256 / o.HD, h = (fblk * 256 % o.HD) >> 8;  // 0 = Q, 1 = K, 2 = V; head
     const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
     float* red = (float*)smem;  // [4][64] cross-wave maxima; the main loop's ring is dead when it is used
+    // the block's parameters (weight row scales and biases of its 256 features, row scales of its 64 tokens) staged in LDS behind the
+    // ring: the epilogue of a four-wave workgroup is a chain of dependent loads, and an LDS read costs a tenth of an L2 round trip
+    float* const p_ws = (float*)(smem + Q8K::SMEM_BYTES);  // [256]
+    float* const p_b = p_ws + 256;                         // [256]
+    float* const p_hs = p_b + 256;                         // [64]
+    p_ws[threadIdx.x] = a.w_scale[fblk * 256 + threadIdx.x];
+    p_b[threadIdx.x] = o.bias[fblk * 256 + threadIdx.x];
+    if (threadIdx.x < 64) p_hs[threadIdx.x] = a.h_scale[t0 + threadIdx.x];
+    // (visible after the first barrier of the main loop)
     I8Acc q[2][2];
     f32x16 v[2][2];
     if (which < 2) {
@@ -69,14 +78,14 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
         const float sc = which == 0 ? o.qscale : 1.0f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float sa = a.h_scale[t0 + j * 32 + col];
+            const float sa = p_hs[j * 32 + col];
             float amax = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                i8_dequant(q[i][j], v[i][j], a.w_scale + f0 + i * 32 + 4 * hf, sa);
+                i8_dequant(q[i][j], v[i][j], p_ws + wf * 64 + i * 32 + 4 * hf, sa);
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const float4 b4 = *(const float4*)(o.bias + f0 + i * 32 + 8 * gq + 4 * hf);
+                    const float4 b4 = *(const float4*)(p_b + wf * 64 + i * 32 + 8 * gq + 4 * hf);
                     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -126,10 +135,10 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             for (int r = 0; r < 16; ++r) tmax[j][r] = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float sw = a.w_scale[f0 + i * 32 + col], bf = o.bias[f0 + i * 32 + col];
+            const float sw = p_ws[wf * 64 + i * 32 + col], bf = p_b[wf * 64 + i * 32 + col];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                i8_dequant_rows(q[i][j], v[i][j], sw, a.h_scale + t0 + j * 32 + 4 * hf);
+                i8_dequant_rows(q[i][j], v[i][j], sw, p_hs + j * 32 + 4 * hf);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     v[i][j][r] += bf;

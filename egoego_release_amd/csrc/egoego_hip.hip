@@ -694,10 +694,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                                1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid, g.Lr};
                     static bool once = false;
                     if (!once) {
-                        HIP_TRY(allow_smem(qkv_i8q_kernel, Q8K::SMEM_BYTES));
+                        HIP_TRY(allow_smem(qkv_i8q_kernel, Q8K::SMEM_BYTES + 4096));
                         once = true;
                     }
-                    qkv_i8q_kernel<<<dim3((3 * HD / BLK_A_F) * (rows / 64)), dim3(256), Q8K::SMEM_BYTES, s>>>(qa, qo);
+                    qkv_i8q_kernel<<<dim3((3 * HD / BLK_A_F) * (rows / 64)), dim3(256), Q8K::SMEM_BYTES + 4096, s>>>(qa, qo);
                     HIP_TRY(hipGetLastError());
                 }
                 {
