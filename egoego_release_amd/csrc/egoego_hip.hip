@@ -154,6 +154,7 @@ struct Workspace {
     float *hB_scale, *F_scale;  // [Mp] their row scales
     int8_t* O8;                 // i8x3 fc: the attention output as int8 slices, slice stride o_plane bytes
     float* O_scale;             // [Mp][H] one scale per row and head
+    int8_t* att_img;         // image region of the split attention forms (see carve) or nullptr
     float *sq8, *sk8, *sv8;  // [B*H][Lp] row scales of the int8 Q / K / V images (attn_core_i8.h; the images alias Q, K, V)
     size_t total;
 };
@@ -181,6 +182,10 @@ static void carve(const egoego_ctx* c, const Geometry& g, char* base, Workspace&
     w.Q = (__bf16*)take(2 * w.qkv_plane * 2);
     w.K = (__bf16*)take(2 * w.qkv_plane * 2);
     w.V = (__bf16*)take(2 * w.qkv_plane * 2);
+    // The split attention forms (attn_split_i8.h; Lp = 128 only) pass their int8 images through the Q and K buffers as ONE region of
+    // [B*H][3][64 KiB] — Q and K are carved back to back and hold 256 KiB per window x head between them — and V's column scales
+    // ([B*H][256] floats) through the V buffer.  nullptr if that ever stops being true: the dispatch then keeps to the one-kernel forms.
+    w.att_img = ((char*)w.K == (char*)w.Q + 2 * w.qkv_plane * 2 && g.Lp == 128) ? (int8_t*)w.Q : nullptr;
     w.O = (__bf16*)take(2 * w.o_plane * 2);
     w.hA8 = (int8_t*)take(2 * w.h_plane);
     w.hA_scale = (float*)take(sizeof(float) * g.Mp);
@@ -651,13 +656,13 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             }
             // the projections as three workgroups per (window, head) + a core launch while they fit the chip at once (attn_split_i8.h);
             // the images go through the Q / K buffers (carved back to back: 256 KiB per window x head), V's column scales through V's
-            if (nw * H * 6 <= ATTN_SPLIT6_MAX_BLOCKS) {  // ... six four-wave workgroups while each of those still gets a CU of its own
-                const AttnSplitBufs sb{(int8_t*)w.Q, w.sq8, w.sk8, (float*)w.V};
+            if (w.att_img && nw * H * 6 <= ATTN_SPLIT6_MAX_BLOCKS) {  // ... six four-wave workgroups while each of those still gets a CU of its own
+                const AttnSplitBufs sb{w.att_img, w.sq8, w.sk8, (float*)w.V};
                 attn_proj6_i8_kernel<<<dim3(nw * H * 6), dim3(256), ATTN_PROJ6_SMEM, s>>>(al, sb);
                 HIP_TRY(hipGetLastError());
                 attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
-            } else if (nw * H * 3 <= ATTN_SPLIT_MAX_BLOCKS) {
-                const AttnSplitBufs sb{(int8_t*)w.Q, w.sq8, w.sk8, (float*)w.V};
+            } else if (w.att_img && nw * H * 3 <= ATTN_SPLIT_MAX_BLOCKS) {
+                const AttnSplitBufs sb{w.att_img, w.sq8, w.sk8, (float*)w.V};
                 attn_proj_i8_kernel<<<dim3(nw * H * 3), dim3(512), ATTN_PROJ_SMEM, s>>>(al, sb);
                 HIP_TRY(hipGetLastError());
                 attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
