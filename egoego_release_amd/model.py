@@ -192,14 +192,18 @@ class CondGaussianDiffusion(nn.Module):
         ):
             self.register_buffer(name, val.to(torch.float32))
         # MI355X-specific knobs (not in the reference): operand precision and the noise source.
-        # PREC_I8X3_FC (default, the fastest mode inside the 1e-3 bar at every batch size): every attention front end, fc and
-        # the FFN on int8 slices — the one-kernel attention layer for windows of 64 < T+1 <= 128 tokens, int8 projections +
-        # int8 core for longer ones (<= 224), int8 projections + split-bf16 core and split-bf16 fc for shorter ones; embed and
-        # linear_out split-bf16.  ~2.4e-4 from the fp32 reference on one forward and on the full chain;
-        # PREC_I8X3: fc stays split-bf16, ~1.3e-4, 1-14 % slower; PREC_BF16X3: split-bf16 everywhere, ~2.5e-5, ~20-25 % slower.
-        # A checkpoint with extreme LayerNorm gains / weight outliers costs the int8 modes precision (one scale per row):
-        # tools/precision_compare.py and tools/hostile_weights_check.py measure it; PREC_BF16X3 is the fallback.
-        self.hip_precision = _lib.PREC_I8X3_FC
+        # PREC_I8X3_FC (9, the fastest mode inside the 1e-3 bar at every batch size): every attention front end, fc, the FFN and
+        # linear_out on int8 slices with int8-only activations between the kernels of a step — the one-kernel attention layer for
+        # windows of 64 < T+1 <= 128 tokens, int8 projections + int8 core for longer ones (<= 224), int8 projections +
+        # split-bf16 core and split-bf16 fc for shorter ones; embed split-bf16.  ~3e-4 from the fp32 reference on one forward and
+        # on the full chain.  PREC_I8X3 (8): fc, linear_out and the residuals stay split-bf16, ~1.3e-4, ~40 % more time per step;
+        # PREC_BF16X3 (3): split-bf16 everywhere, ~2.5e-5, ~80-90 % more.
+        # A checkpoint with LayerNorm gains far above the rest costs the int8 modes precision (one scale per row = 16-bit fixed
+        # point; measured limits in DESIGN.md 3c, tools/hostile_weights_check.py, tools/precision_compare.py).
+        # "auto" (default): 9 unless the checkpoint's LayerNorm gains span more than a factor of 4 (max / median) — then 3 —
+        # decided, with a warning, whenever the weights are (re)packed; `hip_precision_used` tells.
+        self.hip_precision = "auto"
+        self.hip_precision_used = None
         self.hip_graph = True        # replay one captured step per chain (hipGraph); False launches every kernel
         self.sampling_rng = "torch"  # "torch": reference RNG draw order; "philox": in-kernel, shard-invariant
         self.philox_seed = 0
@@ -277,31 +281,44 @@ class CondGaussianDiffusion(nn.Module):
                        objective=self.objective)
             if self.objective not in ("pred_noise", "pred_x0"):
                 raise ValueError(f"unknown objective {self.objective}")
-            self._slot.engine = HipEngine(cfg, self.state_dict(), dev, self.hip_precision,
+            self.hip_precision_used = self._resolve_precision()
+            self._slot.engine = HipEngine(cfg, self.state_dict(), dev, self.hip_precision_used,
                                           0 if self.hip_graph else _lib.FLAG_NO_GRAPH)
             self._slot.key = key
             self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
-            self._warn_if_outlier_heavy()
         return self._slot.engine
 
-    def _warn_if_outlier_heavy(self):
-        """The int8-slice precisions keep one scale per row (16-bit fixed point): a few LayerNorm gains an order of magnitude
-        above the rest cost every other feature of a row that many bits.  Measured (tools/hostile_weights_check.py): 8x gains on
-        six features stay inside the 1e-3 bar in every precision, 25x gains leave it in precision 9 (1.4e-3) and come close in
-        precision 8 (5.5e-4).  Checked once per weight (re)pack; a warning, not a fallback — the caller picks the precision."""
-        if self.hip_precision not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
-            return
+    GAIN_SPREAD_LIMIT = 4.0  # max / median |LayerNorm gain| up to which the int8-slice precisions stay inside the bar in the worst case measured
+
+    def _resolve_precision(self):
+        """The int8-slice precisions keep one scale per row (16-bit fixed point): LayerNorm gains far above the rest cost every
+        other feature of a row that many bits.  Measured: with DIFFERENT features amplified in each LayerNorm
+        (tools/hostile_weights_check.py) 8x gains stay inside the 1e-3 bar in every precision; with the SAME six features
+        amplified in all of them (tools/gain_sweep.py — their outliers compound through the residual stream) precisions 9 and 8
+        alike leave it at 5x (1.3e-3 / 1.2e-3 of |y|max; 5e-4 at 4x) while precision 3 stays below 2.5e-4 up to 25x.  Checked
+        once per weight (re)pack (one host sync): `hip_precision = "auto"` steps down to 3 above a max / median gain of 4; an
+        explicit int8 precision is kept and warned about."""
+        want = self.hip_precision
+        if want != "auto" and want not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
+            return want
         worst = 0.0
         for name, p in self.denoise_fn.named_parameters():
             if name.endswith("layer_norm.weight") and p.numel() > 1:
                 a = p.detach().abs().float()
                 worst = max(worst, float(a.max() / a.median().clamp_min(1e-12)))
-        limit = 10.0 if self.hip_precision == _lib.PREC_I8X3_FC else 20.0
-        if worst > limit:
+        if worst <= self.GAIN_SPREAD_LIMIT:
+            return _lib.PREC_I8X3_FC if want == "auto" else want
+        if want == "auto":
             warnings.warn(
-                f"LayerNorm gains span a factor of {worst:.0f} (max / median): hip_precision={self.hip_precision} keeps one int8-slice "
-                f"scale per row and may leave the 1e-3 bar on such a checkpoint; compare with tools/precision_compare.py or set "
-                f"model.hip_precision = {_lib.PREC_I8X3 if self.hip_precision == _lib.PREC_I8X3_FC else _lib.PREC_BF16X3}", RuntimeWarning, stacklevel=3)
+                f"LayerNorm gains span a factor of {worst:.0f} (max / median): hip_precision='auto' falls back from the int8-slice "
+                f"default (9) to split-bf16 (3) for this checkpoint (~85 % more time per step); tools/precision_compare.py "
+                f"measures what each precision loses on it", RuntimeWarning, stacklevel=4)
+            return _lib.PREC_BF16X3
+        warnings.warn(
+            f"LayerNorm gains span a factor of {worst:.0f} (max / median): hip_precision={want} keeps one int8-slice scale per row "
+            f"and may leave the 1e-3 bar on such a checkpoint; compare with tools/precision_compare.py or set "
+            f"model.hip_precision = {_lib.PREC_BF16X3} (or 'auto')", RuntimeWarning, stacklevel=4)
+        return want
 
     def _check_t(self, t):
         """The reference indexes its schedule buffers with t (`extract`, M:36-39) and the time embedding accepts any
