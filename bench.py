@@ -51,9 +51,9 @@ def tail_flops_per_launch(B, T, d_model=512, n_head=4, d_k=256):
 
 
 def cpu_baseline(cfg, sd, B, T, budget_s=25.0):
-    import torch
     """Time the CPU oracle (fp32 PyTorch restatement of the reference, bit-identical to it) on the
     host cores: whole-batch p_sample steps until ~budget_s of work."""
+    import torch
     from oracle import egoego_oracle as O
     from egoego_release_amd import make_head_windows
     try:
@@ -119,10 +119,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="GLOBAL number of windows (split over the GPUs)")
     ap.add_argument("--window", type=int, default=120)
-    ap.add_argument("--precision", type=int, default=9, choices=(1, 3, 8, 9),
-                    help="9 = int8-slice attention layer, fc and FFN + split-bf16 embed / linear_out (parity-grade, default: the fastest mode "
-                         "inside the 1e-3 bar), 8 = the same with fc on split-bf16 (parity-grade, half the error), 3 = split-bf16 "
-                         "everywhere (parity-grade), 1 = plain bf16 (NOT parity-grade)")
+    ap.add_argument("--precision", default="auto", choices=("auto", "1", "3", "8", "9"),
+                    help="auto (default) = what the module's default picks for these weights by measuring them (model.py _resolve_precision: "
+                         "9, else 8, else 3); 9 = int8-slice attention layer, fc, FFN and linear_out + split-bf16 embed (parity-grade, the "
+                         "fastest mode inside the 1e-3 bar), 8 = the same with fc / linear_out on split-bf16 (parity-grade, half the error), "
+                         "3 = split-bf16 everywhere (parity-grade), 1 = plain bf16 (NOT parity-grade)")
+    ap.add_argument("--weights", default="synthetic", choices=("synthetic", "trained-like"),
+                    help="synthetic: the seeded initialisation-distribution weights; trained-like: the same after --train-steps Adam steps of the "
+                         "module's own training loss on synthetic motion (tools/make_trained_like_checkpoint.py; trained on this GPU before the bench)")
+    ap.add_argument("--train-steps", type=int, default=3000)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step (no hipGraph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="rank 0 saves the gathered poses of the timed call here (tests)")
@@ -168,13 +173,20 @@ def main():
 
     B, T = args.batch, args.window
     cfg = ModelConfig(max_timesteps=T + 1)
-    sd = make_weights(cfg, 0)
+    if args.weights == "trained-like":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from make_trained_like_checkpoint import train_like
+        sd, train_info = train_like(args.train_steps, 0, dev, T)
+        sd = {k: v for k, v in sd.items() if k.startswith("denoise_fn.")}
+    else:
+        sd, train_info = make_weights(cfg, 0), None
     model = CondGaussianDiffusion(**cfg.ctor_kwargs())
     model.load_state_dict(sd, strict=False)
-    model.hip_precision = args.precision
+    model.hip_precision = "auto" if args.precision == "auto" else int(args.precision)
     model.hip_graph = not args.no_graph
     model = model.to(dev)
     eng = model.hip_engine(verify=True)
+    prec = int(model.hip_precision_used)  # what runs: the probe's pick under "auto"
 
     # the GLOBAL batch (every rank holds it: 24 MB per tensor at B=256); rank r samples the contiguous slice
     # dist.shard_bounds gives it (strong scaling: BASELINE configs[2] is B=256 split over the GPUs of the node)
@@ -192,13 +204,14 @@ def main():
     # and runs the collective once so that RCCL's lazy communicator set-up is not in the timed region)
     if W:
         D.sample_sharded(D.hip_steps_fn(model, S - 1, W, seed=7), xs, cm, noise, force_collective=force_coll)
+    timed_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7)  # (checksums the weights once, outside the timed region)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # K steps of this rank's shard (no collective in the loop) ...
-    shard = D.sample_local(D.hip_steps_fn(model, S - 1 - W, K, seed=7), xs, cm, noise)
+    shard = D.sample_local(timed_fn, xs, cm, noise)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     # ... then the ONE all_gather of the path (timed separately as well)
@@ -221,6 +234,8 @@ def main():
     # per-kernel launch durations (HIP events on the launch stream), measured AFTER the timed region on this rank's
     # shard: a few extra steps per kernel with event pairs around every launch of that kernel
     Bl = hi - lo
+    eng = model.hip_engine()  # (the runtime outlier guard may have re-packed in another precision after the timed call)
+    guard_demoted = int(model.hip_precision_used) != prec
     x_l = noise["x_T"][lo:hi].contiguous().clone()
     xc_l = (xs[lo:hi] * (1 - cm[lo:hi]) + cm[lo:hi] * noise["cond"][lo:hi]).contiguous()
     kern = {"qkv": (0.0, 0), "fc_ln": (0.0, 0)}
@@ -233,13 +248,13 @@ def main():
 
     traffic, traffic_src = {}, None
     try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command, summarised under profiles/
-        for name in ("r03_traffic.json", "r02_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(tp):
                 continue
             with open(tp) as f:
                 tj = json.load(f)
-            if (Bl, T, args.precision) == (tj.get("batch"), tj.get("window"), tj.get("precision")):
+            if (Bl, T, prec) == (tj.get("batch"), tj.get("window"), tj.get("precision")) and tj.get("weights", "synthetic") == args.weights:
                 traffic = tj["kernels"]
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc passes of this command; not measured in this run)"
                 break
@@ -249,51 +264,59 @@ def main():
     if rank == 0:
         steps_per_s = K / el
         fl_step = flops_per_window_step(T) * B
-        i8 = args.precision in (8, 9) and 64 < T + 1 <= 128
-        i8_long = args.precision in (8, 9) and T + 1 > 128   # int8 projections written as int8 images + separate int8 attention core
-        half_q = i8 and Bl * 4 * 2 <= 192   # the library's dispatch: two half-query workgroups per (window, head) up to 24 windows
-        split3 = i8 and Bl * 4 * 3 <= 256  # ... and below that the projections as three workgroups per (window, head) + a core launch
-        attn_name = ("attn_proj6_i8_kernel" if (i8 and Bl * 4 * 6 <= 256) else "attn_proj_i8_kernel" if split3 else "attn_layer_i8h_kernel" if half_q else "attn_layer_i8w_kernel") if i8 else ("qkv_i8q_kernel" if i8_long else "qkv_attn_kernel")
-        attn_peak = PEAK_I8_TOPS if (i8 or i8_long) else PEAK_BF16_TFLOPS
-        attn_flops = Bl * 2 * (T + 1) * 512 * 3 * 1024 if i8_long else qkv_attn_flops_per_launch(Bl, T)
-        attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None
-        tail_ach = tail_flops_per_launch(Bl, T) / (t_us * 1e-6) / 1e12 if t_n else None
         L = T + 1
         ms_step = 1e3 * el / K
+        # which kernels ran comes from the library (egoego_last_kernel_name: it records what its dispatch picked for this shape and
+        # precision during the profiled steps above) — no copy of the dispatch rules here
+        attn_full, tail_full = eng.last_kernel("qkv"), eng.last_kernel("fc_ln")
+        attn_name, tail_name = attn_full.split("<")[0], tail_full.split("<")[0]
+        i8_layer = attn_name in ("attn_layer_i8w_kernel", "attn_layer_i8h_kernel", "attn_proj_i8_kernel", "attn_proj6_i8_kernel")
+        i8_long = attn_name == "qkv_i8q_kernel"
+        o8 = prec == 9 and L > 64                      # the attention kernels hand O over as int8 rows (2 B per value)
+        ATTN_TXT = {
+            "attn_layer_i8w_kernel": "Q/K/V projections, softmax and PV of one window x head per 8-wave workgroup, int8 slices; K, V, Q and the probabilities stay in LDS/registers",
+            "attn_layer_i8h_kernel": "the one-kernel int8 attention layer as two half-query workgroups per window x head (small grids)",
+            "attn_proj_i8_kernel": "Q/K/V projections of a window x head as three workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
+            "attn_proj6_i8_kernel": "Q/K/V projections of a window x head as six workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
+            "qkv_i8q_kernel": "Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8_kernel; projection operations only",
+            "qkv_i8_kernel": "Q/K/V projections on int8 slices for the split-bf16 attention core; projection operations only",
+            "qkv_attn_kernel": "fused Q/K/V projection + attention, split-bf16",
+            "qkv_kernel": "Q/K/V projections, split-bf16; projection operations only"}
+        proj_only = attn_name not in ("attn_layer_i8w_kernel", "attn_layer_i8h_kernel", "qkv_attn_kernel")
+        attn_i8 = i8_layer or i8_long or attn_name == "qkv_i8_kernel"
+        attn_peak = PEAK_I8_TOPS if attn_i8 else PEAK_BF16_TFLOPS
+        attn_flops = Bl * 2 * L * 512 * 3 * 1024 if proj_only else qkv_attn_flops_per_launch(Bl, T)
+        attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None
+        tail_ach = tail_flops_per_launch(Bl, T) / (t_us * 1e-6) / 1e12 if t_n else None
+        # algorithmic HBM bytes of one attention-layer launch: the layer input rows in (int8 slices: 2 B per value; split-bf16: 4),
+        # O out (int8 rows with precision 9: 2 B per value; split-bf16: 4) + the three projections' weights once
+        attn_bytes = ((2 if attn_i8 else 4) * Bl * L * 512 + (2 if o8 else 4) * Bl * L * 1024 + (2 if attn_i8 else 4) * 3 * 512 * 1024) if not proj_only else None
+        core_flops = Bl * 4 * L * L * 1024  # QK^T + PV: what north_star words as the "attention-GEMM roofline"
         attn_roof = {
-            "bound": "mfma", "kernel": attn_name + (" (Q/K/V projections, softmax and PV of one window x head per 8-wave workgroup, int8 slices; "
-                                                    "K, V, Q and the probabilities stay in LDS/registers)" if i8 else
-                                                    (" (Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8_kernel; "
-                                                     "projection operations only)" if i8_long else " (fused Q/K/V projection + attention, split-bf16)")),
-            "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if (i8 or i8_long) else "TFLOP/s",
+            "bound": "mfma", "kernel": f"{attn_full} ({ATTN_TXT.get(attn_name, '')})",
+            "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if attn_i8 else "TFLOP/s",
             "frac": (attn_ach / attn_peak) if attn_ach else None,
             "traffic": (traffic.get(attn_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
-            "algorithmic_bytes": (2 * Bl * L * 512 + 4 * Bl * L * 1024 + 3 * 2 * 512 * 1024) if i8 else (4 * Bl * L * (512 + 1024) + 6.3e6),
+            "algorithmic_bytes": attn_bytes,
             "launch_us": k_us, "launches": k_n, "share_of_step": 4 * k_us / (1e3 * ms_step) if k_n else None,
+            "attention_core_share_of_operations": None if proj_only else core_flops / attn_flops,
             "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time, measured on rank 0's shard right after "
                     "the timed region; three MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe "
-                    "utilisation is 3x this fraction"}
-        Lp = 32 if L <= 32 else 64 if L <= 64 else 128 if L <= 128 else 224       # padded rows per window (make_geometry)
-        rows_p = (Bl * Lp + 255) // 256 * 256                                     # padded token rows of this rank's shard
-        fc8 = args.precision == 9 and T + 1 > 64
-        big_tail = rows_p // 128 > 128 and not fc8   # the library's dispatch (run_chunk_np: tb_b <= 128 or int8 fc -> tail_kernel)
-        tail_name = ("layer_tail_i8_kernel" if args.precision == 8 else "layer_tail_kernel") if big_tail else "tail_kernel"
-        ffn_txt = "FFN on int8 slices" if args.precision in (8, 9) else "FFN split-bf16"
-        tail_txt = ((" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 64 tokens, two workgroups per CU, LDS-ring operands; "
-                     f"fc split-bf16, {ffn_txt}" + (" in two passes into one int32 accumulator)" if args.precision == 8 else ")"))
-                    if big_tail else
-                    ((" (fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 32 tokens, all three contractions on int8 slices: weights "
-                      "streamed into registers, the attention output by LDS-DMA chunks with one integer chain per head, the LayerNorm-1 rows "
-                      "and the hidden rows resident in LDS; " + ("two 4-wave workgroups per CU)" if rows_p // 32 > 256 else "one 8-wave workgroup per CU)"))
-                     if fc8 else
-                     (" (the same three GEMMs per 32/64 tokens for small batches: weights streamed into registers, activations by LDS-DMA "
-                      f"chunks; fc split-bf16, {ffn_txt})")))
+                    "utilisation is 3x this fraction.  The kernel is one launch for projections + QK^T + softmax + PV: the attention "
+                    "core alone (QK^T + PV) is `attention_core_share_of_operations` of its operations and has no launch time of its own"}
+        fc8 = prec == 9 and L > 64
+        TAIL_TXT = {
+            "tail_kernel": "fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 32/64 tokens: weights streamed into registers, activations by "
+                           "LDS-DMA chunks (precision 9: all three contractions on int8 slices, one integer chain per head in fc, LayerNorm-1 rows and hidden rows resident in LDS)",
+            "layer_tail_i8_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands; fc split-bf16, FFN on int8 slices in two passes into one int32 accumulator",
+            "layer_tail_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands, split-bf16",
+            "gemm_kernel:EpiResLN": "fc + residual + LayerNorm alone (unfused small-batch form; FFN-1 / FFN-2 are separate launches not in this figure)"}
         # the peak of the MFMAs the kernel issues: all int8 (precision 9), fc bf16 + FFN int8 (precision 8: the two halves of its
         # FLOPs at 2.5 and 5 P, i.e. 3333 T together), all bf16 (precisions 3, 1)
-        tail_peak = PEAK_I8_TOPS if fc8 else (2.0 / (1.0 / PEAK_BF16_TFLOPS + 1.0 / PEAK_I8_TOPS) if args.precision == 8 else PEAK_BF16_TFLOPS)
-        tail_unit = "TOP/s (int8 MFMA, 2 per MAC)" if fc8 else ("TFLOP/s (fc on bf16 MFMAs, FFN on int8 MFMAs)" if args.precision == 8 else "TFLOP/s")
+        tail_peak = PEAK_I8_TOPS if fc8 else (2.0 / (1.0 / PEAK_BF16_TFLOPS + 1.0 / PEAK_I8_TOPS) if prec == 8 else PEAK_BF16_TFLOPS)
+        tail_unit = "TOP/s (int8 MFMA, 2 per MAC)" if fc8 else ("TFLOP/s (fc on bf16 MFMAs, FFN on int8 MFMAs)" if prec == 8 else "TFLOP/s")
         tail_roof = {
-            "bound": "mfma", "kernel": tail_name + tail_txt,
+            "bound": "mfma", "kernel": f"{tail_full} ({TAIL_TXT.get(tail_name, '')})",
             "achieved": tail_ach, "peak": tail_peak, "unit": tail_unit, "frac": (tail_ach / tail_peak) if tail_ach else None,
             "traffic": (traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
             # precision 9: the attention output (1024 x 2 B), the residual rows in and the layer's rows out (512 x 2 B each) per token
@@ -303,6 +326,7 @@ def main():
             "note": "measured like the attention-layer kernel; 3 MFMAs are issued per product (split-bf16: K=16 per MFMA; int8 slices: K=32 per "
                     "MFMA at the same issue time); normalised by the peak of the MFMAs the kernel actually issues"}
         dominant, other = (attn_roof, tail_roof) if (k_us or 0) >= (t_us or 0) else (tail_roof, attn_roof)
+        probe = model.hip_precision_probe
         out_json = {
             "metric": f"diffusion-steps/sec (B={B}, T={T}, 22-joint)",
             "value": steps_per_s,
@@ -316,11 +340,17 @@ def main():
             "vs_baseline": None,
             "dtype": {8: "i8x3 + bf16x3 (attention layer and FFN: 2 x int8 slices per operand, int32 accumulate; embed, fc, linear_out: split-bf16, fp32 accumulate)",
                       9: "i8x3 + bf16x3 (attention layer, fc, FFN and linear_out: 2 x int8 slices per operand, int32 accumulate; embed: split-bf16, fp32 accumulate)",
-                      3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)", 1: "bf16"}[args.precision],
+                      3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)", 1: "bf16"}[prec],
+            "precision": prec,
+            "precision_requested": args.precision,
+            # what hip_precision = "auto" (the module default) picks for THESE weights, and the measurement it picked it on
+            "precision_auto": prec if args.precision == "auto" else None,
+            "precision_probe": probe,
+            "weights": args.weights if train_info is None else {"kind": args.weights, **train_info},
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: B={B} windows x T={T} frames x 198 feats split over {world} GPU(s) "
                                    f"({Bl} windows on rank 0), 1000-step DDPM chain (steps {S - 1 - W}..{S - W - K} timed), in-kernel "
-                                   f"Philox noise keyed by the global window index, synthetic seeded weights",
+                                   f"Philox noise keyed by the global window index, {'synthetic seeded' if train_info is None else 'trained-like'} weights",
                        "global_windows": B, "windows_per_gpu": Bl, "window_len": T,
                        "parallelism": f"window-sharded x{world} (dist.sample_sharded), one all_gather of the poses inside the timed region",
                        "hip_graph": not args.no_graph},
@@ -332,6 +362,8 @@ def main():
             "collective_backend": (backend if dist else None),
             "gather_ms": gather_ms if dist else None,
             "sample_ms": sample_ms,
+            "outlier_row_max": model.hip_outlier_seen,
+            "outlier_guard_demoted_after_timed_call": guard_demoted,
             "roofline": dominant,
             "roofline_second_kernel": other,
         }

@@ -7,9 +7,9 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegoego_hip.so")
-PERFDEBUG_LIB_PATH = os.path.join(_PKG, "libegoego_hip_perfdebug.so")  # tools/ only: `build --perfdebug`
+PERFDEBUG_LIB_PATH = os.path.join(os.path.dirname(_PKG), "tools", "_build", "libegoego_hip_perfdebug.so")  # tools/ only: `build --perfdebug`
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_NO_GRAPH = 1
 PRED_NOISE, PRED_X0 = 0, 1
 NOISE_INJECTED, NOISE_PHILOX, NOISE_NONE = 0, 1, 2
@@ -47,7 +47,8 @@ class Schedule(C.Structure):
 EXPORTS = ["egoego_abi_version", "egoego_last_error", "egoego_ctx_create", "egoego_ctx_destroy",
            "egoego_load_weights", "egoego_load_schedule", "egoego_workspace_bytes", "egoego_denoise",
            "egoego_p_sample", "egoego_sample_loop", "egoego_ddim_loop", "egoego_rot6d_to_matrix", "egoego_convert_model_res", "egoego_window_prefix", "egoego_window_condition",
-           "egoego_profile_begin", "egoego_profile_end", "egoego_debug_stage"]
+           "egoego_profile_begin", "egoego_profile_end", "egoego_debug_stage", "egoego_last_kernel_name", "egoego_outlier_stats"]
+OUTLIER_SITES = 16
 
 _lib = None
 
@@ -97,6 +98,9 @@ def load():
     lib.egoego_profile_begin.argtypes = [vp, i32]
     lib.egoego_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]
     lib.egoego_debug_stage.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, vp, sz, vp]
+    lib.egoego_last_kernel_name.argtypes = [vp, i32]
+    lib.egoego_last_kernel_name.restype = C.c_char_p
+    lib.egoego_outlier_stats.argtypes = [vp, i32, i32, vp, sz, c_float_p, i32, i32, vp]
     if lib.egoego_abi_version() != ABI_VERSION:
         raise EgoEgoHipError(f"ABI mismatch: library {lib.egoego_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

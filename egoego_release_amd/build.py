@@ -7,6 +7,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libegoego_hip.so")
+PERFDEBUG_DIR = os.path.join(os.path.dirname(PKG), "tools", "_build")
 SOURCES = ["egoego_hip.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "egoego_hip.h")]
 
@@ -28,10 +29,13 @@ def is_stale():
 def build(force=False, verbose=False, perfdebug=False, defines=(), tag=""):
     """Compile csrc/*.hip -> egoego_release_amd/libegoego_hip.so (gfx950 only).
 
-    perfdebug=True builds libegoego_hip_perfdebug.so instead: the same sources with -DEGOEGO_PERFDEBUG (per-block
+    perfdebug=True builds tools/_build/libegoego_hip_perfdebug.so instead: the same sources with -DEGOEGO_PERFDEBUG (per-block
     timestamps, stage ablation; plus any extra `defines` such as EGOEGO_ABLATE_MAINLOOP=1) for tools/*_trace.py.
     The product library contains none of that."""
-    out = LIB.replace(".so", "_perfdebug" + (f"_{tag}" if tag else "") + ".so") if perfdebug else LIB
+    out = LIB
+    if perfdebug:  # tools-only builds stay out of the package directory
+        os.makedirs(PERFDEBUG_DIR, exist_ok=True)
+        out = os.path.join(PERFDEBUG_DIR, "libegoego_hip_perfdebug" + (f"_{tag}" if tag else "") + ".so")
     if not force and not perfdebug and not is_stale():
         return out
     # -ffp-contract=on: a multiply and an add fuse only where ONE source expression holds both (hipcc's default, "fast", also

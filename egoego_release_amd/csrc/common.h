@@ -204,7 +204,12 @@ struct StepState {
     const float* prefix;   // [B][prefix_len][D] in-painting source or nullptr
     uint64_t seed;         // Philox key
     int64_t window_offset; // global index of window 0 (shard-invariant noise)
+    // Outlier monitor of the int8-slice precisions (egoego_outlier_stats): site 2 * layer + (0: LayerNorm-1, 1: LayerNorm-2) holds
+    // the bit pattern of max |value| over every row that epilogue has quantised (one scale per row) since the last reset —
+    // positive floats order like their bit patterns, so the kernels use one atomicMax per workgroup.  Layers >= 8 are not recorded.
+    unsigned ln_max[16];
 };
+static constexpr int OUTLIER_SITES = 16;
 
 // --------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based generator + Box-Muller: four N(0,1) per call.

@@ -100,6 +100,7 @@ struct egoego_ctx {
     // profiling
     int prof_id;
     std::vector<hipEvent_t> prof_events;
+    const char* last_kernel[EGOEGO_K_COUNT];  // the kernel variant each launch site of a step last dispatched to (egoego_last_kernel_name)
 };
 
 static const int N_MODEL = 512;
@@ -366,6 +367,18 @@ template <class K>
 static hipError_t allow_smem(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
+// hipFuncSetAttribute applies to the CURRENT device's copy of the kernel, so the dynamic-LDS opt-in of a launch site is done once
+// per device a context lives on (the header allows one context per device), not once per process.  Every entry point has called
+// hipSetDevice(ctx->device) by the time a launch site runs.
+struct DevOnce {
+    unsigned long long mask = 0;  // devices (hipGetDevice ordinal, < 64) this launch site has opted in on
+    int dev = 0;
+    bool pending() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        return !(mask & (1ull << (dev & 63)));
+    }
+    void done() { mask |= 1ull << (dev & 63); }
+};
 
 // GEMM tile configurations (features x tokens per block), chosen by measurement on MI355X
 // (tools/kernel_times.py, tools/block_trace.py, EGOEGO_ABLATE):
@@ -392,10 +405,10 @@ static const int BLK_A_F = 256, BLK_A_T = 128, BLK_B_T = 128;
 template <class C, class Epi>
 static int launch_gemm(const GemmOperands& g, const Epi& epi, hipStream_t s) {
     auto kern = gemm_kernel<C, Epi>;
-    static bool once = false;
-    if (!once) {
+    static DevOnce once;
+    if (once.pending()) {
         HIP_TRY(allow_smem(kern, C::SMEM_BYTES));
-        once = true;
+        once.done();
     }
     kern<<<dim3(g.nfb * g.ntb), dim3(C::NT), C::SMEM_BYTES, s>>>(g, epi);
     HIP_TRY(hipGetLastError());
@@ -406,10 +419,10 @@ template <int KT, int NP>
 static int launch_attn_kt(const AttnArgs& a, int BH, hipStream_t s) {
     auto kern = attn_kernel<KT, NP>;
     constexpr int smem = 2 * KT * NP * 4096;
-    static bool once = false;
-    if (!once) {
+    static DevOnce once;
+    if (once.pending()) {
         HIP_TRY(allow_smem(kern, smem));
-        once = true;
+        once.done();
     }
     kern<<<dim3((KT + 3) / 4, BH), dim3(256), smem, s>>>(a);
     HIP_TRY(hipGetLastError());
@@ -429,17 +442,20 @@ static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
 
 // Fused small-batch tail (tail_fused.h): 64-token workgroups when they fill the CUs exactly once, 32-token ones below.
 template <bool FFN8>
-static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
-    static bool once = false;
-    if (!once) {
+static int launch_tail_f(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_t s) {
+    static DevOnce once;
+    if (once.pending()) {
         HIP_TRY(allow_smem((tail_kernel<2, FFN8, false>), tail_smem_bytes(2)));
         HIP_TRY(allow_smem((tail_kernel<1, FFN8, false>), tail_smem_bytes(1)));
-        once = true;
+        once.done();
     }
-    if (rows / 64 >= 256)
+    if (rows / 64 >= 256) {
+        c->last_kernel[EGOEGO_K_FC_LN] = FFN8 ? "tail_kernel<2,true,false>" : "tail_kernel<2,false,false>";
         tail_kernel<2, FFN8, false><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
-    else
+    } else {
+        c->last_kernel[EGOEGO_K_FC_LN] = FFN8 ? "tail_kernel<1,true,false>" : "tail_kernel<1,false,false>";
         tail_kernel<1, FFN8, false><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -469,24 +485,27 @@ static int launch_tail_f(const TailArgs& ta, int rows, hipStream_t s) {
 #ifndef TAIL8_MAX_BLOCKS
 #define TAIL8_MAX_BLOCKS 256
 #endif
-static int launch_tail(const TailArgs& ta, int rows, hipStream_t s, bool resident = false) {
+static int launch_tail(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_t s, bool resident = false) {
     if (ta.fc8) {
         // int8 fc: 32-token workgroups at every batch size.  (64-token ones — tail_kernel<2, true, true>, fc in two feature
         // passes, one workgroup per CU — measured slower: 250 against 235 us per launch at B=256, 0.94 against 0.80 ms per step at
         // B=128: what a large grid needs is more bytes in flight per CU, not fewer bytes per token.)
-        static bool once = false;
-        if (!once) {
+        static DevOnce once;
+        if (once.pending()) {
             HIP_TRY(allow_smem((tail_kernel<1, true, true, true>), tail_smem_bytes(1) + TAIL_PAR_BYTES));
             HIP_TRY(allow_smem((tail_kernel<1, true, true, false, 8>), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES));
             HIP_TRY(allow_smem((tail_kernel<1, true, true, true, 4, true>), tail_smem_bytes(1) + TAIL_PAR_BYTES + TAIL_RES_BYTES));
             HIP_TRY(allow_smem((tail_kernel<1, true, true, false, 8, true>), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES + TAIL_RES_BYTES));
-            once = true;
+            once.done();
         }
         if (resident) {  // precision 9's product path: the FFN operands never leave the CU (tail_fused.h RES)
-            if (rows / 32 > TAIL8_MAX_BLOCKS)
+            if (rows / 32 > TAIL8_MAX_BLOCKS) {
+                c->last_kernel[EGOEGO_K_FC_LN] = "tail_kernel<1,true,true,true,4,true>";
                 tail_kernel<1, true, true, true, 4, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1) + TAIL_PAR_BYTES + TAIL_RES_BYTES, s>>>(ta);
-            else
+            } else {
+                c->last_kernel[EGOEGO_K_FC_LN] = "tail_kernel<1,true,true,false,8,true>";
                 tail_kernel<1, true, true, false, 8, true><<<dim3(rows / 32), dim3(512), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES + TAIL_RES_BYTES, s>>>(ta);
+            }
             HIP_TRY(hipGetLastError());
             return 0;
         }
@@ -494,14 +513,17 @@ static int launch_tail(const TailArgs& ta, int rows, hipStream_t s, bool residen
         // 235 us per launch of the 512-register four-wave build).  At most one workgroup per CU: the eight-wave build, the same
         // 256-register waves as ONE workgroup (measured against the four-wave builds, which tie there: 31.5 against 39.5 us per
         // launch at B=32, 0.316 against 0.344 ms per step; 0.387 against 0.415 at B=64; 0.304 against 0.332 at B=1)
-        if (rows / 32 > TAIL8_MAX_BLOCKS)
+        if (rows / 32 > TAIL8_MAX_BLOCKS) {
+            c->last_kernel[EGOEGO_K_FC_LN] = "tail_kernel<1,true,true,true>";
             tail_kernel<1, true, true, true><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1) + TAIL_PAR_BYTES, s>>>(ta);
-        else
+        } else {
+            c->last_kernel[EGOEGO_K_FC_LN] = "tail_kernel<1,true,true,false,8>";
             tail_kernel<1, true, true, false, 8><<<dim3(rows / 32), dim3(512), tail_smem_bytes(1, 8) + TAIL_PAR_BYTES, s>>>(ta);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    return ta.ffn8 ? launch_tail_f<true>(ta, rows, s) : launch_tail_f<false>(ta, rows, s);
+    return ta.ffn8 ? launch_tail_f<true>(c, ta, rows, s) : launch_tail_f<false>(c, ta, rows, s);
 }
 
 // The direct-operand embed / linear_out kernels run 32-token workgroups (TT = 1) at every size they are used for
@@ -509,11 +531,11 @@ static int launch_tail(const TailArgs& ta, int rows, hipStream_t s, bool residen
 
 template <int TT>
 static int launch_embed_tt(const EmbedArgs& ea, int rows, hipStream_t s) {
-    static bool once = false;
-    if (!once) {
+    static DevOnce once;
+    if (once.pending()) {
         HIP_TRY(allow_smem((embed_kernel<TT, 4>), TT * 32 * 1024));
         HIP_TRY(allow_smem((embed_kernel<TT, 8>), TT * 32 * 1024));
-        once = true;
+        once.done();
     }
     if (rows / (32 * TT) <= EMBED8_MAX_BLOCKS)  // at most one workgroup per CU: eight waves
         embed_kernel<TT, 8><<<dim3(rows / (32 * TT)), dim3(512), TT * 32 * 1024, s>>>(ea);
@@ -524,11 +546,11 @@ static int launch_embed_tt(const EmbedArgs& ea, int rows, hipStream_t s) {
 }
 template <int TT, bool I8>
 static int launch_out_tt(const OutArgs& oa, int rows, hipStream_t s) {
-    static bool once = false;
-    if (!once) {
+    static DevOnce once;
+    if (once.pending()) {
         HIP_TRY(allow_smem((out_kernel<TT, 1, I8>), TT * 32 * 1024));
         HIP_TRY(allow_smem((out_kernel<TT, 2, I8>), TT * 32 * 1024));
-        once = true;
+        once.done();
     }
     const int nb = rows / (32 * TT);
     if (nb <= 128)  // fewer token blocks than half the CUs: two workgroups per token block, 128 features each
@@ -543,10 +565,10 @@ template <int KT>
 static int launch_attn_core8_kt(const AttnCore8Args& a, int BH, hipStream_t s) {
     auto kern = attn_core_i8_kernel<KT>;
     constexpr int smem = 2 * (2 * KT * 4 * 1024) + 2 * KT * 32 * 4;  // two buffers of half an image (both slices) + key scales
-    static bool once = false;
-    if (!once) {
+    static DevOnce once;
+    if (once.pending()) {
         HIP_TRY(allow_smem(kern, smem));
-        once = true;
+        once.done();
     }
     kern<<<dim3((KT + 3) / 4, BH), dim3(256), smem, s>>>(a);
     HIP_TRY(hipGetLastError());
@@ -594,7 +616,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
     const bool i8_path = NP == 2 && prec_i8(c);  // every layer input also as int8 rows
     // precision 9, windows of more than 64 tokens: a layer's inter-kernel activations exist as int8 rows ONLY (residuals are
     // rebuilt from them); the split-bf16 copies are written just for the debug stops and, after the last layer, for linear_out
-    const bool act8_only = i8_path && c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7) && io.stop_stage < 0;
+    // (the Q/K/V debug stops run the split-bf16 projections, which read the split-bf16 embed rows; every other stop taps the int8 rows
+    // of the product path itself: egoego_debug_stage)
+    const bool dbg_qkv_any = io.stop_stage == EGOEGO_DBG_Q || io.stop_stage == EGOEGO_DBG_K || io.stop_stage == EGOEGO_DBG_V;
+    const bool act8_only = i8_path && c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7) && !dbg_qkv_any;
     __bf16* const embed_out = act8_only ? nullptr : w.hA;
     {
         ProfScope ps(c, EGOEGO_K_EMBED, s);
@@ -603,6 +628,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             EmbedArgs ea{w.xall, w.xall_plane, c->KE / 16, c->w_embed, (size_t)N_MODEL * c->KE,
                          EpiEmbed<2, 4, 0>{c->b_embed, c->pe, c->tt_table, w.t_idx, embed_out, w.h_plane, g.Lr, g.T, g.B, i8_path ? w.hA8 : nullptr,
                                            w.h_plane, i8_path ? w.hA_scale : nullptr, io.state, io.ts}};
+            c->last_kernel[EGOEGO_K_EMBED] = "embed_kernel";
             if (int r = launch_embed_tt<1>(ea, rows, s)) return r;
         } else if (i8_path) {
             // 512-feature x 128-token blocks, eight waves, one workgroup per CU (the epilogue sees whole rows and also writes them as
@@ -610,8 +636,10 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             // blocks, two per CU: 53.7 us per launch at B=256 against 51.8)
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, 1, rows / 128, row0 / 128 EG_DBG(, g_ablate, g_trace)};
             EpiEmbed<NP, 4, 128> e{c->b_embed, c->pe, c->tt_table, w.t_idx, embed_out, w.h_plane, g.Lr, g.T, g.B, w.hA8, w.h_plane, w.hA_scale, io.state, io.ts};
+            c->last_kernel[EGOEGO_K_EMBED] = "gemm_kernel:EpiEmbed";
             if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
         } else {
+            c->last_kernel[EGOEGO_K_EMBED] = "gemm_kernel:EpiEmbed";
             GemmOperands go{c->w_embed, (size_t)N_MODEL * c->KE, w.xall, w.xall_plane, c->KE / 16, N_MODEL / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
             EpiEmbed<NP> e{c->b_embed, c->pe, c->tt_table, w.t_idx, w.hA, w.h_plane, g.Lr, g.T, g.B, nullptr, 0, nullptr, io.state, io.ts};
             if (int r = launch_gemm<CfgA<NP>>(go, e, s)) return r;
@@ -638,6 +666,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // the layer's output also as int8 slices: the next layer's projections consume them
         const bool q8_out = i8 && (li + 1 < c->cfg.n_dec_layers || act8_only);  // (precision 9's product path: linear_out reads int8 rows too)
         int8_t* const q8p = q8_out ? w.hA8 : nullptr;
+        // outlier monitor of the row-quantising LayerNorm epilogues (StepState::ln_max; read through egoego_outlier_stats)
+        unsigned* const om1 = li < OUTLIER_SITES / 2 ? &w.state->ln_max[2 * li] : nullptr;
+        unsigned* const om2 = li < OUTLIER_SITES / 2 ? &w.state->ln_max[2 * li + 1] : nullptr;
         if (fused_attn && i8) {
             ProfScope ps(c, EGOEGO_K_QKV, s);
             AttnLayerArgs al{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, L.b_qkv, w.hA8, w.h_plane, w.hA_scale, w.O, w.o_plane, HD / 16,
@@ -645,33 +676,38 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             if (fc8) {
                 al.o8 = w.O8; al.o8_plane = w.o_plane; al.o_scale = w.O_scale;
             }
-            static bool once = false;
-            if (!once) {
+            static DevOnce once;
+            if (once.pending()) {
                 HIP_TRY(allow_smem(attn_layer_i8w_kernel, AL_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_proj_i8_kernel, ATTN_PROJ_SMEM));
                 HIP_TRY(allow_smem(attn_core_s_kernel, ATTN_CORE_S_SMEM));
                 HIP_TRY(allow_smem(attn_proj6_i8_kernel, ATTN_PROJ6_SMEM));
-                once = true;
+                once.done();
             }
             // the projections as three workgroups per (window, head) + a core launch while they fit the chip at once (attn_split_i8.h);
             // the images go through the Q / K buffers (carved back to back: 256 KiB per window x head), V's column scales through V's
             if (w.att_img && nw * H * 6 <= ATTN_SPLIT6_MAX_BLOCKS) {  // ... six four-wave workgroups while each of those still gets a CU of its own
                 const AttnSplitBufs sb{w.att_img, w.sq8, w.sk8, (float*)w.V};
+                c->last_kernel[EGOEGO_K_QKV] = "attn_proj6_i8_kernel";
                 attn_proj6_i8_kernel<<<dim3(nw * H * 6), dim3(256), ATTN_PROJ6_SMEM, s>>>(al, sb);
                 HIP_TRY(hipGetLastError());
                 attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
             } else if (w.att_img && nw * H * 3 <= ATTN_SPLIT_MAX_BLOCKS) {
                 const AttnSplitBufs sb{w.att_img, w.sq8, w.sk8, (float*)w.V};
+                c->last_kernel[EGOEGO_K_QKV] = "attn_proj_i8_kernel";
                 attn_proj_i8_kernel<<<dim3(nw * H * 3), dim3(512), ATTN_PROJ_SMEM, s>>>(al, sb);
                 HIP_TRY(hipGetLastError());
                 attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
             } else
             // up to 24 windows x 4 heads: two workgroups per (window, head), half the queries each (attn_layer_i8h.h)
-            if (nw * H * 2 <= ATTN_HALF_MAX_BLOCKS)
+            if (nw * H * 2 <= ATTN_HALF_MAX_BLOCKS) {
+                c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8h_kernel";
                 attn_layer_i8h_kernel<<<dim3(nw * H * 2), dim3(512), AL_SMEM_BYTES, s>>>(al);
-            else
+            } else {
+                c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8w_kernel";
                 attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AL_SMEM_BYTES, s>>>(al);
+            }
             HIP_TRY(hipGetLastError());
         } else if (fused_attn) {
             // --- fused: Q/K/V projections of one (window, head) + its attention (TM:71-88)
@@ -679,11 +715,12 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, 0 EG_DBG(, g_ablate, g_trace)};
             auto kern = qkv_attn_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>, CfgQ<NP>, 4, NP>;
             constexpr int smem = CfgA<NP>::SMEM_BYTES > 2 * 4 * NP * 4096 ? CfgA<NP>::SMEM_BYTES : 2 * 4 * NP * 4096;
-            static bool once = false;
-            if (!once) {
+            static DevOnce once;
+            if (once.pending()) {
                 HIP_TRY(allow_smem(kern, smem));
-                once = true;
+                once.done();
             }
+            c->last_kernel[EGOEGO_K_QKV] = "qkv_attn_kernel";
             kern<<<dim3(nw * H), dim3(CfgA<NP>::NT), smem, s>>>(go, eqk, ev, aa, H);
             HIP_TRY(hipGetLastError());
         } else {
@@ -697,11 +734,12 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, rows / 64, 2 * HD / BLK_A_F};
                     Qkv8Out qo{(int8_t*)w.Q, (int8_t*)w.K, (int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, L.b_qkv,
                                1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid, g.Lr};
-                    static bool once = false;
-                    if (!once) {
+                    static DevOnce once;
+                    if (once.pending()) {
                         HIP_TRY(allow_smem(qkv_i8q_kernel, Q8K::SMEM_BYTES + 4096));
-                        once = true;
+                        once.done();
                     }
+                    c->last_kernel[EGOEGO_K_QKV] = "qkv_i8q_kernel";
                     qkv_i8q_kernel<<<dim3((3 * HD / BLK_A_F) * (rows / 64)), dim3(256), Q8K::SMEM_BYTES + 4096, s>>>(qa, qo);
                     HIP_TRY(hipGetLastError());
                 }
@@ -712,6 +750,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     if (fc8) {
                         ca.o8 = w.O8; ca.o8_plane = w.o_plane; ca.o_scale = w.O_scale;
                     }
+                    c->last_kernel[EGOEGO_K_ATTN] = "attn_core_i8_kernel";
                     if (int r = launch_attn_core8(ca, g.KT, g.B * H, s)) return r;
                 }
             } else if (i8 && !dbg_qkv) {
@@ -719,22 +758,24 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 ProfScope ps(c, EGOEGO_K_QKV, s);
                 QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, tb_a, 2 * HD / BLK_A_F};
                 auto kern = qkv_i8_kernel<EpiQK<NP>, EpiV<NP>>;
-                static bool once = false;
-                if (!once) {
+                static DevOnce once;
+                if (once.pending()) {
                     HIP_TRY(allow_smem(kern, AL8K::SMEM_BYTES));
-                    once = true;
+                    once.done();
                 }
+                c->last_kernel[EGOEGO_K_QKV] = "qkv_i8_kernel";
                 kern<<<dim3((3 * HD / BLK_A_F) * tb_a), dim3(256), AL8K::SMEM_BYTES, s>>>(qa, eqk, ev);
                 HIP_TRY(hipGetLastError());
             } else {
                 ProfScope ps(c, EGOEGO_K_QKV, s);
                 GemmOperands go{L.w_qkv, (size_t)3 * HD * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 3 * HD / BLK_A_F, tb_a, t0_a EG_DBG(, g_ablate, g_trace)};
                 auto kern = qkv_kernel<CfgA<NP>, EpiQK<NP>, CfgAV<NP>, EpiV<NP>>;
-                static bool once = false;
-                if (!once) {
+                static DevOnce once;
+                if (once.pending()) {
                     HIP_TRY(allow_smem(kern, CfgA<NP>::SMEM_BYTES));
-                    once = true;
+                    once.done();
                 }
+                c->last_kernel[EGOEGO_K_QKV] = "qkv_kernel";
                 kern<<<dim3(go.nfb * go.ntb), dim3(CfgA<NP>::NT), CfgA<NP>::SMEM_BYTES, s>>>(go, eqk, ev, 2 * HD / BLK_A_F);
                 HIP_TRY(hipGetLastError());
             }
@@ -742,6 +783,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
             if (!core8) {
                 ProfScope ps(c, EGOEGO_K_ATTN, s);
+                c->last_kernel[EGOEGO_K_ATTN] = "attn_kernel";
                 if (int r = launch_attn<NP>(aa, g.KT, nw * H, s)) return r;
             }
         }
@@ -772,6 +814,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 ta.relu = EpiTiled<true, 2>{L.b_1, w.F, w.h_plane, N_MODEL / 16};
                 ta.w2 = L.w_2; ta.w2_plane = (size_t)N_MODEL * N_MODEL;
                 ta.ln2 = EpiResLN<2, 4, 0>{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                ta.outlier = om1; ta.outlier_rows = g.Mvalid;  // (om2 = om1 + 1)
                 if (act8_only) {
                     // residuals from the int8 rows; no split-bf16 rows at all (linear_out reads the last layer's int8 rows)
                     ta.ln1.res8 = w.hA8; ta.ln1.res8_plane = w.h_plane; ta.ln1.res8_scale = w.hA_scale; ta.ln1.out = nullptr;
@@ -780,7 +823,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 }
                 ta.stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
                 EG_DBG(ta.trace = g_trace;)
-                if (int r = launch_tail(ta, rows, s, act8_only)) return r;
+                if (int r = launch_tail(c, ta, rows, s, act8_only)) return r;
                 if (last_dbg) return 0;
                 continue;
             }
@@ -792,18 +835,21 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             const size_t wp8 = (size_t)N_MODEL * N_MODEL / 2;  // slice stride in the main loop's 2-byte units
             GemmOperands g1{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, nb, b0 EG_DBG(, g_ablate, g_trace)};
             EpiResLN<NP, 4, 64> e1{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f, w.hB8, w.h_plane, w.hB_scale};
+            e1.outlier = om1; e1.outlier_rows = g.Mvalid;
             GemmOperands g2{(const __bf16*)L.w_1_8, wp8, (const __bf16*)w.hB8, w.h_plane / 2, N_MODEL / 32, 1, nb, b0 EG_DBG(, 0, nullptr)};
             EpiReluQ8<4, 64> e2{L.b_1, w.F8, w.h_plane, w.F_scale};
             GemmOperands g3{(const __bf16*)L.w_2_8, wp8, (const __bf16*)w.F8, w.h_plane / 2, N_MODEL / 32, 1, nb, b0 EG_DBG(, 0, nullptr)};
             EpiResLN<NP, 4, 64> e3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+            e3.outlier = om2; e3.outlier_rows = g.Mvalid;
             auto kern = layer_tail_i8_kernel<CfgBs<NP>, CfgT8a, CfgT8b, EpiResLN<NP, 4, 64>, EpiReluQ8<4, 64>>;
             static_assert(CfgT8a::SMEM_BYTES <= CfgBs<2>::SMEM_BYTES && CfgT8b::SMEM_BYTES <= CfgBs<2>::SMEM_BYTES, "the int8 passes reuse the split-bf16 ring");
-            static bool once = false;
-            if (!once) {
+            static DevOnce once;
+            if (once.pending()) {
                 HIP_TRY(allow_smem(kern, CfgBs<NP>::SMEM_BYTES + 6144));
-                once = true;
+                once.done();
             }
             const int stop = !last_dbg ? 0 : (io.stop_stage == EGOEGO_DBG_ATTN_LN ? 1 : (io.stop_stage == EGOEGO_DBG_FFN_HIDDEN ? 2 : 0));
+            c->last_kernel[EGOEGO_K_FC_LN] = "layer_tail_i8_kernel";
             kern<<<dim3(nb), dim3(CfgBs<NP>::NT), CfgBs<NP>::SMEM_BYTES + 6144, s>>>(g1, e1, g2, L.s_1, e2, g3, L.s_2, e3, stop);
             HIP_TRY(hipGetLastError());
             if (last_dbg) return 0;
@@ -820,12 +866,14 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             EpiTiled<true, NP> e2{L.b_1, w.F, w.h_plane, N_MODEL / 16};
             GemmOperands g3{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, nb, b0 EG_DBG(, g_ablate, g_trace ? g_trace + 8192 : nullptr)};
             EpiResLN<NP, 4, 64> e3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+            e3.outlier = om2; e3.outlier_rows = g.Mvalid;
             auto kern = layer_tail_kernel<CfgBs<NP>, EpiResLN<NP, 4, 64>, EpiTiled<true, NP>>;
-            static bool once = false;
-            if (!once) {
+            static DevOnce once;
+            if (once.pending()) {
                 HIP_TRY(allow_smem(kern, CfgBs<NP>::SMEM_BYTES));
-                once = true;
+                once.done();
             }
+            c->last_kernel[EGOEGO_K_FC_LN] = "layer_tail_kernel";
             kern<<<dim3(nb), dim3(CfgBs<NP>::NT), CfgBs<NP>::SMEM_BYTES, s>>>(g1, e1, g2, e2, g3, e3);
             HIP_TRY(hipGetLastError());
             continue;
@@ -833,6 +881,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // --- fc + residual + LayerNorm (+ padding mask) (TM:92-93, 135)
         {
             ProfScope ps(c, EGOEGO_K_FC_LN, s);
+            c->last_kernel[EGOEGO_K_FC_LN] = "gemm_kernel:EpiResLN";
             if (small_ln) {
                 GemmOperands go{L.w_fc, (size_t)N_MODEL * HD, w.O, w.o_plane, HD / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
                 if (go.ntb <= SMALL_GRID) {
@@ -869,14 +918,17 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 if (go.ntb <= SMALL_GRID) {
                     GemmOperands gt{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, rows / 32, row0 / 32 EG_DBG(, g_ablate, g_trace)};
                     EpiResLN<NP, 4, 32> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                    e.outlier = om2; e.outlier_rows = g.Mvalid;
                     if (int r = launch_gemm<CfgBt<NP>>(gt, e, s)) return r;
                 } else {
                     EpiResLN<NP, 4, 64> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                    e.outlier = om2; e.outlier_rows = g.Mvalid;
                     if (int r = launch_gemm<CfgBs<NP>>(go, e, s)) return r;
                 }
             } else {
                 GemmOperands go{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, tb_b, t0_b EG_DBG(, g_ablate, g_trace)};
                 EpiResLN<NP, 4, 128> e{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                    e.outlier = om2; e.outlier_rows = g.Mvalid;
                 if (int r = launch_gemm<CfgB<NP>>(go, e, s)) return r;
             }
         }
@@ -887,21 +939,24 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         if (NP == 2 && direct_io) {
             OutArgs oa{w.hA, w.h_plane, c->w_out, (size_t)c->NOUT * N_MODEL, EpiOut<2>{io.out},
                        w.hA8, w.h_plane, w.hA_scale, c->w_out_8, (size_t)c->NOUT * N_MODEL, c->s_out};
+            c->last_kernel[EGOEGO_K_OUT] = "out_kernel";
             if (int r = act8_only ? launch_out_tt<1, true>(oa, rows, s) : launch_out_tt<1, false>(oa, rows, s)) return r;
         } else if (NP == 2 && act8_only) {
             // the last layer's output exists as int8 rows only: linear_out on int8 slices, 256 features x 128 tokens per eight-wave workgroup
             GemmOperands go{(const __bf16*)c->w_out_8, (size_t)c->NOUT * N_MODEL / 2, (const __bf16*)w.hA8, w.h_plane / 2, N_MODEL / 32, 1, rows / 128, row0 / 128 EG_DBG(, 0, nullptr)};
             auto kern = gemm_i8_kernel<AW8K, EpiOut<2>>;
-            static bool once = false;
-            if (!once) {
+            static DevOnce once;
+            if (once.pending()) {
                 HIP_TRY(allow_smem(kern, AW8K::SMEM_BYTES));
-                once = true;
+                once.done();
             }
+            c->last_kernel[EGOEGO_K_OUT] = "gemm_i8_kernel:EpiOut";
             kern<<<dim3(go.ntb), dim3(AW8K::NT), AW8K::SMEM_BYTES, s>>>(go, c->s_out, w.hA_scale, EpiOut<2>{io.out});
             HIP_TRY(hipGetLastError());
         } else {
             GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c EG_DBG(, g_ablate, g_trace)};
             EpiOut<NP> e{io.out};
+            c->last_kernel[EGOEGO_K_OUT] = "gemm_kernel:EpiOut";
             if (tb_c <= SMALL_GRID) {
                 GemmOperands gs{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, rows / 64, row0 / 64 EG_DBG(, g_ablate, g_trace)};
                 if (int r = launch_gemm<CfgC2<NP>>(gs, e, s)) return r;
@@ -1003,6 +1058,7 @@ int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
     c->S = cfg->num_timesteps;
     c->have_weights = c->have_sched = false;
     c->prof_id = -1;
+    for (int i = 0; i < EGOEGO_K_COUNT; ++i) c->last_kernel[i] = "";
     c->w_embed = c->w_out = nullptr;
     c->cap_stream = nullptr;
     c->stage_next = 0;
@@ -1289,9 +1345,9 @@ static int run_steps(egoego_ctx* c, const Geometry& g, const Workspace& w, StepI
                 return fail(EGOEGO_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
             }
             if (c->graphs.size() >= 8) {
-                // the evicted graph may still be executing on a caller stream: drain this one before destroying it
-                // (rare: the ninth distinct step shape of a context)
-                HIP_TRY(hipStreamSynchronize(s));
+                // the evicted graph may still be executing (graphs are shared across calls, and a caller may have moved to
+                // another stream since): drain the device before destroying it (rare: the ninth distinct step shape of a context)
+                HIP_TRY(hipDeviceSynchronize());
                 (void)hipGraphExecDestroy(c->graphs.front().exec);
                 (void)hipGraphDestroy(c->graphs.front().graph);
                 c->graphs.erase(c->graphs.begin());
@@ -1467,6 +1523,29 @@ int egoego_debug_ablate(int bits) {
 }
 #endif
 
+int egoego_outlier_stats(egoego_ctx* c, int B, int T, void* d_ws, size_t ws_bytes, float* host_out, int n_out, int reset, void* stream) {
+    if (!c) return fail(EGOEGO_E_INVALID, "null context");
+    if (n_out < 0 || n_out > OUTLIER_SITES || (n_out && !host_out)) return fail(EGOEGO_E_INVALID, "bad output array (at most %d sites)", OUTLIER_SITES);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Geometry g;
+    Workspace w;
+    if (int r = prepare(c, B, T, d_ws, ws_bytes, g, w)) return r;
+    if (n_out) {
+        unsigned bits[OUTLIER_SITES];
+        HIP_TRY(hipMemcpyAsync(bits, w.state->ln_max, sizeof(unsigned) * n_out, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < n_out; ++i) memcpy(&host_out[i], &bits[i], sizeof(float));
+    }
+    if (reset) HIP_TRY(hipMemsetAsync(w.state->ln_max, 0, sizeof(unsigned) * OUTLIER_SITES, s));
+    return 0;
+}
+
+const char* egoego_last_kernel_name(const egoego_ctx* c, int kernel_id) {
+    if (!c || kernel_id < 0 || kernel_id >= EGOEGO_K_COUNT) return "";
+    return c->last_kernel[kernel_id];
+}
+
 int egoego_profile_begin(egoego_ctx* c, int kernel_id) {
     if (!c || kernel_id < 0 || kernel_id >= EGOEGO_K_COUNT) return fail(EGOEGO_E_INVALID, "bad kernel id");
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -1514,13 +1593,22 @@ int egoego_debug_stage(egoego_ctx* c, const float* d_x, const float* d_xc, const
     if (int r = run_denoiser(c, g, w, io, s)) return r;
     const int lo = c->cfg.precision != EGOEGO_PREC_BF16X1;
     const int L = g.L;
+    // precision 9, windows of more than 64 tokens: the stops run the PRODUCT kernels (run_chunk_np: act8_only), whose inter-kernel
+    // activations exist as int8 rows only — the taps read those
+    const bool rows8 = c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7);
     switch (stage) {
         case EGOEGO_DBG_EMBED:
         case EGOEGO_DBG_LAYER_OUT:
-            k_unpack_tiled<<<2048, 256, 0, s>>>(w.hA, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
+            if (rows8)
+                k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.hA8, w.h_plane, w.hA_scale, N_MODEL, g.Lp, L, B, d_out, 1);
+            else
+                k_unpack_tiled<<<2048, 256, 0, s>>>(w.hA, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_ATTN_LN:
-            k_unpack_tiled<<<2048, 256, 0, s>>>(w.hB, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
+            if (rows8)
+                k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.hB8, w.h_plane, w.hB_scale, N_MODEL, g.Lp, L, B, d_out, 1);
+            else
+                k_unpack_tiled<<<2048, 256, 0, s>>>(w.hB, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_FFN_HIDDEN:
             if (prec_i8(c))  // the hidden activations exist as int8 rows only
@@ -1529,7 +1617,7 @@ int egoego_debug_stage(egoego_ctx* c, const float* d_x, const float* d_xc, const
                 k_unpack_tiled<<<2048, 256, 0, s>>>(w.F, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_ATTN_OUT:
-            if (c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7))  // int8 rows, one scale per row and head
+            if (rows8)  // int8 rows, one scale per row and head
                 k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.O8, w.o_plane, w.O_scale, c->HD, g.Lp, L, B, d_out, c->H);
             else
                 k_unpack_tiled<<<2048, 256, 0, s>>>(w.O, w.o_plane, c->HD, g.Lp, L, B, d_out, lo);

@@ -589,6 +589,7 @@ struct EpiReluQ8 {
     float* q8_scale;     // [Mp]
     char* lds_q8;
     float* lds_scale;
+    int tok_base;        // added to t0 for the MEMORY rows only (the LDS-resident tail calls with block-local t0 = 0; its debug tap also stores to memory)
     // q: the integer sums of an int8-slice contraction (I8Acc or I8One); sw / sa: weight-row and activation-row scales.
     // LEAN (256-register waves, two per SIMD): two sweeps over the INTEGER sums, one tile at a time (a tile's 16 scales and
     // 16 biases in registers; the fences keep hipcc from hoisting every tile's loads to the top): the first only takes the
@@ -647,7 +648,7 @@ struct EpiReluQ8 {
             inv[j] = rmax > 0.f ? I8_QMAX / rmax : 0.f;
             if (wf == 0 && hf == 0) {
                 const float sc = rmax > 0.f ? rmax / I8_QMAX : 0.f;
-                if (q8_scale) q8_scale[t0 + j * 32 + col] = sc;
+                if (q8_scale) q8_scale[tok_base + t0 + j * 32 + col] = sc;
                 if (lds_scale) lds_scale[j * 32 + col] = sc;
             }
         }
@@ -669,7 +670,7 @@ struct EpiReluQ8 {
                 u32x4 s1, s2;
                 quant16(t, inv[j], s1, s2);
                 if (q8) {
-                    const size_t idx = acc_slot_i8(t0 + j * 32 + col, f0 + i * 32, hf, 16);
+                    const size_t idx = acc_slot_i8(tok_base + t0 + j * 32 + col, f0 + i * 32, hf, 16);
                     *(u32x4*)(q8 + idx) = s1;
                     *(u32x4*)(q8 + q8_plane + idx) = s2;
                 }
@@ -810,6 +811,9 @@ struct EpiResLN {
     // optional (the LDS-resident tail): the int8 rows ALSO / ONLY into LDS as the next contraction's operand chunks (see EpiReluQ8)
     char* lds_q8;
     float* lds_scale;
+    // optional: outlier monitor (common.h StepState::ln_max) — the largest row maximum this launch quantises, one atomicMax per workgroup
+    unsigned* outlier;
+    int outlier_rows;  // token tiles reaching beyond this row hold the padding of the last token block (uninitialised inputs): not recorded
     // rr: the residual as int8 rows in registers (instead of res / res8); keep: receives the int8 rows this call produces
     template <int FT, int TT, class ResR = NoRows, class KeepR = NoRows>
     __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int wf, int wt, char* smem, const ResR* rr = nullptr,
@@ -985,6 +989,25 @@ struct EpiResLN {
                     }
                 }
             }
+#ifndef EGOEGO_NO_MONITOR
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);  // (after the stores: the monitor must not lengthen any live range above)
+            if (outlier && wf == 0) {
+                // the row maxima once more from LDS (nothing is kept live across the quantisation above; red3 stays intact until
+                // the next barrier); both half-waves hold the same 32 tokens
+                float omax = 0.f;
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    float rmax = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWF; ++w) rmax = fmaxf(rmax, red3[slot[j] + w * BT]);
+                    if (t0 + j * 32 + 32 <= outlier_rows) omax = fmaxf(omax, rmax);  // (wave-uniform: whole token tiles only)
+                }
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+                if (lane == 0) atomicMax(outlier, __builtin_bit_cast(unsigned, omax));
+            }
+#endif
         }
     }
 };

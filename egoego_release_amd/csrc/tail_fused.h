@@ -80,6 +80,8 @@ struct TailArgs {
     const float* s_w2;
     EpiReluQ8<4, 0> relu8;   // bias, int8 output rows + scales
     int stop;                // debug taps: 1 = return after LayerNorm-1, 2 = after FFN-1, 0 = run everything
+    unsigned* outlier;       // outlier monitor (StepState::ln_max + 2 * layer: LayerNorm-1's site, LayerNorm-2's right behind) or nullptr
+    int outlier_rows;        // rows below this index are recorded
     EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][32] phase timestamps or nullptr
 };
 
@@ -384,8 +386,9 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
     mark(0);
     f32x16 acc[FT][TT];
     // epilogue structs carry the large-batch kernels' code; only the tokens-per-block template argument differs
-    auto as_ln = [&](const EpiResLN<2, 4, 0>& e) {
-        return EpiResLN<2, NWV, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale, e.res8, e.res8_plane, e.res8_scale};
+    auto as_ln = [&](const EpiResLN<2, 4, 0>& e, int which = 0) {
+        return EpiResLN<2, NWV, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale, e.res8, e.res8_plane, e.res8_scale, nullptr, nullptr,
+                                     a.outlier ? a.outlier + which : nullptr, a.outlier_rows};
     };
     // All-int8 build: the ten per-feature parameter vectors of the three epilogues (weight row scales, biases, LayerNorm gains
     // and shifts) are staged in LDS once per workgroup — the epilogues of a 32-token workgroup are load-latency chains, and an
@@ -462,10 +465,11 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
         G8::prime(wq, (const __bf16*)a.w1_8, a.w8_plane / 2, 16, wave * FT, lane);
         {
             auto e = as_ln(a.ln1);
-            e.q8 = nullptr; e.q8_scale = nullptr;
+            if (a.stop != 1) { e.q8 = nullptr; e.q8_scale = nullptr; }  // (debug tap 1: the LayerNorm-1 rows also go to memory, a.ln1.q8)
             e.lds_q8 = act; e.lds_scale = ls1;
             e.template run<FT, TT, NoRows, Rows8<FT>>(acc, wave * FT * 32, tok0, lane, wave, 0, red, nullptr, &h1);
         }
+        if (a.stop == 1) return;
         __syncthreads();  // the rows and their scales are in LDS
         mark(2);
         I8Acc q[FT][TT];
@@ -475,16 +479,19 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
         {
             // (the barrier inside the epilogue, between its row-maximum exchange and its stores, is also what lets the stores
             // overwrite the LayerNorm-1 rows: every wave has left its k-loop by then)
-            const EpiReluQ8<NWV, TOK> e{a.relu8.bias, nullptr, 0, nullptr, act, ls2};
+            // (debug tap 2: the hidden rows also go to memory, a.relu8.q8 — the epilogue then needs the block's first token for them)
+            const bool tap = a.stop == 2;
+            const EpiReluQ8<NWV, TOK> e{a.relu8.bias, tap ? a.relu8.q8 : nullptr, a.relu8.q8_plane, tap ? a.relu8.q8_scale : nullptr, act, ls2, tap ? tok0 : 0};
             e.template run<false, I8Acc, FT, TT>(q, p_sw1, ls1, wave * FT * 32, 0, lane, wave, 0, red);
         }
+        if (a.stop == 2) return;
         __syncthreads();
         mark(4);
         ffn_resident(q, a.w2_8, 9);
         mark(5);
         i8_dequant_tile<false>(q, acc, p_sw2, ls2, wave * FT * 32, 0, lane);
         {
-            auto e = as_ln(a.ln2);
+            auto e = as_ln(a.ln2, 1);
             e.res8 = nullptr;
             e.template run<FT, TT, Rows8<FT>, NoRows>(acc, wave * FT * 32, tok0, lane, wave, 0, red, &h1, nullptr);
         }
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
             mark(5);
             i8_dequant_tile<false>(q, acc, p_sw2, a.relu8.q8_scale, wave * FT * 32, tok0, lane);
         }
-        as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
+        as_ln(a.ln2, 1).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
         EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
         mark(6);
         return;
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
     // =============================================================== 3. FFN w_2 + residual + LayerNorm (TM:111-114, 139)
     G::run(acc, a.relu.out, a.relu.out_plane, 32, a.w2, a.w2_plane, act, tt0, wave, lane, [&] { mark(9); });
     mark(5);
-    as_ln(a.ln2).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
+    as_ln(a.ln2, 1).template run<FT, TT>(acc, wave * FT * 32, tok0, lane, wave, 0, red);
     EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
     mark(6);
     }

@@ -59,11 +59,21 @@ def sample_sharded(sample_fn, x_start, cond_mask, init_noise, group=None, force_
 
 
 def hip_sample_fn(model, seed=0):
-    """sample_fn for `sample_sharded` that runs the HIP path with in-kernel Philox noise."""
+    """sample_fn for `sample_sharded` that runs the HIP path with in-kernel Philox noise.
+
+    ALWAYS Philox: the per-step draws are keyed by (seed; global window index, timestep, frame, feature), which is what makes the
+    result independent of the number of ranks.  The reference's torch-RNG draw order (`model.sampling_rng = "torch"`, one
+    `randn_like` of the WHOLE batch per step, M:253) cannot be reproduced by a shard that only holds part of the batch; a caller
+    who needs the reference's exact draws samples unsharded through `model.sample()`.
+
+    The weights are checksummed against the packed copy once, here (in-place updates made before this call are picked up); the
+    returned function then reuses the context without re-checksumming — make a new function after updating weights."""
     from . import _lib
 
+    model.hip_engine(verify=True)
+
     def fn(xs, cm, noise, window_offset):
-        eng = model.hip_engine(verify=True)  # chain-level entry point: in-place weight updates are picked up
+        eng = model.hip_engine()
         dev = model.betas.device
         x = noise["x_T"].to(dev, torch.float32).contiguous().clone()
         if x.shape[0] == 0:
@@ -72,24 +82,75 @@ def hip_sample_fn(model, seed=0):
         x_cond = (xs * (1.0 - cm) + cm * noise["cond"].to(dev)).float().contiguous()
         S = model.num_timesteps
         eng.sample_loop_(x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
+        model._outlier_guard(eng, x, x_cond)
         return x
 
     return fn
 
 
 def hip_steps_fn(model, t_start, n_steps, seed=0):
-    """Like hip_sample_fn, but `n_steps` ancestral steps from timestep `t_start` downwards (a slice of the chain):
-    what bench.py times."""
+    """Like hip_sample_fn (Philox draws, weights checksummed once at creation), but `n_steps` ancestral steps from timestep
+    `t_start` downwards (a slice of the chain): what bench.py times."""
     from . import _lib
 
+    model.hip_engine(verify=True)
+
     def fn(xs, cm, noise, window_offset):
-        eng = model.hip_engine(verify=True)
+        eng = model.hip_engine()
         dev = model.betas.device
         x = noise["x_T"].to(dev, torch.float32).contiguous().clone()
         if x.shape[0] == 0:
             return x
         x_cond = (xs.to(dev) * (1.0 - cm.to(dev)) + cm.to(dev) * noise["cond"].to(dev)).float().contiguous()
         eng.sample_loop_(x, x_cond, t_start, n_steps, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
+        model._outlier_guard(eng, x, x_cond)
         return x
 
     return fn
+
+
+# ------------------------------------------------------------------------------------------ sequence-level sharding of the harness
+def harness_noise(n_pairs, n_frames, seq_len, seed=0, d_feats=198):
+    """The initial draws of the sliding-window harness for ALL (sequence, sample) pairs, from a private seeded CPU generator:
+    {'x_all': [n, T, D], 'cond': [per window [n, Tw, D]]} — every rank draws the same and slices its pairs, so x_T and the
+    condition noise of a pair do not depend on the sharding (the per-step draws are Philox keyed by the global pair index)."""
+    from . import harness
+    g = torch.Generator().manual_seed(int(seed) * 104729 + 7)
+    x_all = torch.randn((n_pairs, n_frames, d_feats), generator=g)
+    cond = [torch.randn((n_pairs, n, d_feats), generator=g) for _, n in harness.window_spans(n_frames, seq_len)]
+    return {"x_all": x_all, "cond": cond}
+
+
+def harness_sharded(model, ds, head_pose, sample_bs=1, seed=0, parents=None, group=None, force_collective=False, harness_fn=None):
+    """`Trainer.full_body_gen_cond_head_pose_sliding_window` (trainer_amass_cond_motion_diffusion.py:261-276) over the GPUs of a
+    node, sharded by SEQUENCE: head_pose [Bseq, T, 7] (every rank holds all of it: it is small) holds Bseq
+    head trajectories, each sampled `sample_bs` times (run_egoego.py:146-148 repeats a sequence's head pose sample_bs times).
+    The Bseq * sample_bs (sequence, sample) pairs — sequence-major, like that repeat — are split contiguously over the ranks;
+    the windows of one pair never leave its rank (window k + 1 in-paints the tail of window k, M:395-467).  No collective in
+    the loop; ONE all_gather of the stitched (axis-angle, root) result ends the call.  Draws: `harness_noise` + Philox keyed by
+    the global pair index, so the result is the same for any number of ranks.
+    Returns (local axis-angle [Bseq * sample_bs, T', 22, 3], root [Bseq * sample_bs, T', 3]) on every rank.
+    harness_fn(head_pose_slice, noise_slice, pair_offset) -> (aa, root): stand-in for tests; default = the HIP harness."""
+    from . import harness
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    pairs = head_pose.repeat_interleave(sample_bs, dim=0)
+    n, n_frames = pairs.shape[0], pairs.shape[1]
+    seq_len = model.seq_len
+    noise = harness_noise(n, n_frames, seq_len, seed)
+    lo, hi = shard_bounds(n, rank, world)
+    if harness_fn is None:
+        dev = model.betas.device
+
+        def harness_fn(hp, nz, off):
+            return harness.full_body_gen_cond_head_pose_sliding_window(model, ds, hp.to(dev), noise=nz, parents=parents, window_offset=off)
+    t_out = harness.output_frames(n_frames, seq_len)
+    if hi > lo:
+        nz = {"x_all": noise["x_all"][lo:hi], "cond": [c[lo:hi] for c in noise["cond"]]}
+        aa, root = harness_fn(pairs[lo:hi], nz, lo)
+        local = torch.cat((aa.reshape(hi - lo, t_out, 66), root.reshape(hi - lo, t_out, 3)), dim=-1).float().contiguous()
+    else:  # more ranks than pairs: this rank still joins the collective, with an empty slice on its device
+        local = torch.zeros((0, t_out, 69), device=model.betas.device, dtype=torch.float32)
+    if dist.is_initialized():
+        local = gather_windows(local, n, group, force=force_collective)
+    return local[..., :66].reshape(n, t_out, 22, 3), local[..., 66:]

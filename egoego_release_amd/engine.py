@@ -99,8 +99,24 @@ class HipEngine:
                 self._ws.clear()
             ws = torch.empty(n + 256, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
+            off = (-ws.data_ptr()) % 256
+            # a fresh workspace holds undefined bytes: clear its outlier monitor (no sync)
+            _lib.check(self.lib.egoego_outlier_stats(self._ctx, B, T, ws.data_ptr() + off, ws.numel() - off, None, 0, 1, self._stream()))
         off = (-ws.data_ptr()) % 256
         return ws.data_ptr() + off, ws.numel() - off
+
+    def outlier_stats(self, B, T, reset=True):
+        """Largest |value| every row-quantising LayerNorm epilogue has seen on the (B, T) workspace since the last reset:
+        a list of 2 * n_dec_layers floats (layer-major: self_attn.layer_norm, pos_ffn.layer_norm); synchronises the stream."""
+        n = min(_lib.OUTLIER_SITES, 2 * self.cfg["n_dec_layers"])
+        out = (C.c_float * n)()
+        ws, nb = self.workspace(B, T)
+        _lib.check(self.lib.egoego_outlier_stats(self._ctx, B, T, ws, nb, out, n, 1 if reset else 0, self._stream()))
+        return [float(v) for v in out]
+
+    def last_kernel(self, kernel):
+        """Name of the kernel variant the launch site `kernel` ('qkv', 'attn', 'fc_ln', 'embed', 'out', ...) last dispatched to."""
+        return self.lib.egoego_last_kernel_name(self._ctx, _lib.KERNEL_NAMES[kernel]).decode()
 
     def _chk(self, t, shape=None, dtype=torch.float32):
         if not t.is_cuda or t.device.index != self.dev_index:

@@ -213,13 +213,34 @@ def _window_prefix_hip(ds, aa, root, n_last, parents=None):
     return out
 
 
+def window_spans(num_frames, seq_len):
+    """(first frame, length) of every window the sliding-window loop runs over a `num_frames` trajectory (M:350-356): stride
+    seq_len - 10, a trailing window of at most 10 frames is dropped."""
+    stride = seq_len - OVERLAP
+    spans = []
+    for t_idx in range(0, num_frames, stride):
+        n = min(seq_len, num_frames - t_idx)
+        if n <= seq_len - stride:
+            break
+        spans.append((t_idx, n))
+    return spans
+
+
+def output_frames(num_frames, seq_len):
+    """Frames of the stitched result of the sliding-window loop: the first window whole, the later ones without their 10 overlap frames."""
+    spans = window_spans(num_frames, seq_len)
+    return sum(n for _, n in spans) - OVERLAP * max(0, len(spans) - 1)
+
+
 @torch.no_grad()
 def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos, global_head_jquat, cond_mask,
-                                             noise=None, parents=None):
+                                             noise=None, parents=None, window_offset=0):
     """M:329-467.  Windows of `model.seq_len` frames, stride seq_len-10; window k+1 is conditioned on the
     last 10 frames of window k, re-canonicalised, by overwriting its first 10 frames after every step.
 
-    noise (tests): {'x_all': [B,T,D], 'cond': [per-window [B,Tw,D]], 'steps': [per-window [S,B,Tw,D]]}.
+    noise: {'x_all': [B,T,D], 'cond': [per-window [B,Tw,D]], 'steps': [per-window [S,B,Tw,D]]} injects every draw (tests);
+    without 'steps' the per-step draws are in-kernel Philox keyed by (philox_seed + window; window_offset + b, ...), i.e. by the
+    GLOBAL sequence index — what dist.harness_sharded uses so that the result does not depend on how sequences are sharded.
     """
     eng = model.hip_engine(verify=True)
     parents = _parents_of(ds, parents)
@@ -258,13 +279,15 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
         cn = noise["cond"][w_idx].to(device) if noise is not None else torch.randn_like(x_start)
         x_cond = (x_start * (1.0 - cm) + cm * cn).float().contiguous()
         pfx = prefix if t_idx > 0 else None
-        if noise is not None:
+        if noise is not None and "steps" in noise:
             eng.sample_loop_(curr_x, x_cond, S - 1, S, noise=noise["steps"][w_idx].to(device).float().contiguous(), prefix=pfx)
-        elif model.sampling_rng == "philox":
+        elif model.sampling_rng == "philox" or noise is not None:
             eng.sample_loop_(curr_x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=model.philox_seed + w_idx,
-                             prefix=pfx)
+                             window_offset=window_offset, prefix=pfx)
         else:
             model._torch_rng_chain(eng, curr_x, x_cond, S, pfx)
+        model._outlier_guard(eng, curr_x, x_cond)  # (may re-pack in another precision: take the engine afresh for the next window)
+        eng = model.hip_engine()
         aa, root, head = convert_model_res_to_data(ds, curr_x, recover, cur_jpos, parents)
         if t_idx == 0:
             whole_aa, whole_root, whole_head = aa, root, head
@@ -298,21 +321,21 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
 
 @torch.no_grad()
 def sample_sliding_window_w_canonical(model, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None,
-                                      parents=None):
+                                      parents=None, window_offset=0):
     model.denoise_fn.eval()
     res = p_sample_loop_sliding_window_w_canonical(model, ds, x_start.shape, global_head_jpos, global_head_jquat,
-                                                   cond_mask, noise=noise, parents=parents)
+                                                   cond_mask, noise=noise, parents=parents, window_offset=window_offset)
     model.denoise_fn.train()
     return res
 
 
 @torch.no_grad()
-def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None, parents=None):
+def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None, parents=None, window_offset=0):
     """head_pose [B,T,7] = xyz + quaternion (w,x,y,z) -> (local axis-angle [B,T',22,3], root [B,T',3])."""
     jpos, jquat = head_pose[:, :, :3], head_pose[:, :, 3:]
     data = torch.zeros(head_pose.shape[0], head_pose.shape[1], 198, device=head_pose.device)
     return sample_sliding_window_w_canonical(model, ds, jpos, jquat, data, prep_head_condition_mask(data), noise=noise,
-                                             parents=parents)
+                                             parents=parents, window_offset=window_offset)
 
 
 # ------------------------------------------------------------------------------------------ checkpoints

@@ -147,6 +147,9 @@ class _EngineSlot:
         self.engine, self.key, self.fingerprint = None, None, None
         self.ramp = None       # fingerprint weights (one per packed element)
         self.noise_buf = None  # scratch of the torch-RNG chain, reused across sample() calls
+        self.envelope = None   # per LayerNorm site: the largest row maximum the pack-time probe has validated (runtime guard)
+        self.demoted = False   # the runtime guard measured the int8 precision outside the limit on live inputs: "auto" now means 3
+        self.force_repack = False  # ... and asked for the re-pack that applies it (a re-pack for any other reason clears `demoted`)
 
     def __deepcopy__(self, memo):
         return _EngineSlot()
@@ -200,10 +203,18 @@ class CondGaussianDiffusion(nn.Module):
         # PREC_BF16X3 (3): split-bf16 everywhere, ~2.5e-5, ~80-90 % more.
         # A checkpoint with LayerNorm gains far above the rest costs the int8 modes precision (one scale per row = 16-bit fixed
         # point; measured limits in DESIGN.md 3c, tools/hostile_weights_check.py, tools/precision_compare.py).
-        # "auto" (default): 9 unless the checkpoint's LayerNorm gains span more than a factor of 4 (max / median) — then 3 —
-        # decided, with a warning, whenever the weights are (re)packed; `hip_precision_used` tells.
+        # "auto" (default): decided by MEASUREMENT whenever the weights are (re)packed (`_resolve_precision`): the int8 precisions'
+        # x0 predictions on a fixed probe batch are compared with split-bf16's on the same device, and 9, else 8, is taken only if it
+        # stays within PROBE_LIMIT; `hip_precision_used` / `hip_precision_probe` tell what was picked and what was measured.  While an
+        # int8 precision runs, the LayerNorm epilogues record their largest row maxima (egoego_outlier_stats); at the end of a
+        # chain `_outlier_guard` compares them with what the probe saw and, beyond that envelope, re-measures on the chain's own
+        # tensors and steps "auto" down to 3.
         self.hip_precision = "auto"
         self.hip_precision_used = None
+        self.hip_precision_probe = None   # what the pack-time probe measured: {"errors": {9: .., 8: ..}, "limit": .., "row_max": [..]}
+        self.hip_probe_at_pack = True     # False: skip the probe (auto = 9, absolute envelope for the runtime guard)
+        self.hip_outlier_guard = True     # False: no read-back (and no stream sync) at the end of a chain
+        self.hip_outlier_seen = None      # per LayerNorm site, the largest row maximum of the last guarded chain
         self.hip_graph = True        # replay one captured step per chain (hipGraph); False launches every kernel
         self.sampling_rng = "torch"  # "torch": reference RNG draw order; "philox": in-kernel, shard-invariant
         self.philox_seed = 0
@@ -229,13 +240,16 @@ class CondGaussianDiffusion(nn.Module):
     @torch.no_grad()
     def _weights_fingerprint(self):
         """Device-side checksum of everything packed into the HIP context (one concatenation, two reductions, one host
-        sync): a position-weighted signed sum (weights ramp over [1, 2), so sign flips, swaps and permutations move it)
+        sync): a position-weighted signed sum (hashed weights in [1, 2), so sign flips, swaps and permutations move it)
         and the sum of squares, both accumulated in float64.  A checksum, not a proof: an update that happens to
         preserve both goes unnoticed — call invalidate_engine() when in doubt."""
         flat = torch.cat([t.detach().reshape(-1).float() for t in self._packed_tensors()])
         ramp = self._slot.ramp
         if ramp is None or ramp.shape != flat.shape or ramp.device != flat.device:
-            ramp = self._slot.ramp = 1.0 + torch.arange(flat.numel(), device=flat.device, dtype=torch.float32) / flat.numel()
+            # position weights in [1, 2) from an integer hash of the index (Knuth's multiplier, 24 bits kept: exact in fp32), so that
+            # neighbours get unrelated weights whatever the element count (a linear fp32 ramp repeats values beyond 2^23 elements)
+            idx = torch.arange(flat.numel(), device=flat.device, dtype=torch.int64)
+            ramp = self._slot.ramp = 1.0 + ((idx * 2654435761) & 0xFFFFFF).to(torch.float32) / float(1 << 24)
         fp = torch.stack(((flat * ramp).sum(dtype=torch.float64), (flat * flat).sum(dtype=torch.float64)))
         return tuple(fp.tolist())
 
@@ -247,6 +261,7 @@ class CondGaussianDiffusion(nn.Module):
             self._slot.engine.close()
         self._slot.engine, self._slot.key, self._slot.fingerprint = None, None, None
         self._slot.noise_buf = None
+        self._slot.envelope, self._slot.demoted, self._slot.force_repack = None, False, False
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -271,10 +286,15 @@ class CondGaussianDiffusion(nn.Module):
                 f"device first (it is on {dev}); there is no CPU fallback")
         key = self._engine_key()
         fp = self._weights_fingerprint() if verify else None
-        stale = self._slot.engine is None or self._slot.key != key or (verify and self._slot.fingerprint != fp)
+        stale = (self._slot.engine is None or self._slot.key != key or (verify and self._slot.fingerprint != fp)
+                 or self._slot.force_repack)
         if stale:
             if self._slot.engine is not None:
                 self._slot.engine.close()
+                self._slot.engine = None
+            if not self._slot.force_repack:
+                self._slot.demoted = False  # new weights / device / settings: measured afresh
+            self._slot.force_repack = False
             d = self.denoise_fn
             cfg = dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k,
                        d_v=d.d_v, max_timesteps=d.max_timesteps, num_timesteps=int(self.betas.shape[0]),
@@ -288,37 +308,146 @@ class CondGaussianDiffusion(nn.Module):
             self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
         return self._slot.engine
 
-    GAIN_SPREAD_LIMIT = 4.0  # max / median |LayerNorm gain| up to which the int8-slice precisions stay inside the bar in the worst case measured
+    PROBE_LIMIT = 6e-4       # largest |x0(int8 slices) - x0(split-bf16)| on the probe forwards for which an int8 precision is picked (0.6 of the 1e-3 bar)
+    ENVELOPE_MARGIN = 1.5    # the runtime guard re-measures when a LayerNorm row maximum exceeds this multiple of what the probe validated
+    ENVELOPE_ABSOLUTE = 8.0  # ... or this value when no probe ran (rows of the reference's initialisation peak at 4-5)
+
+    def _x0_from_output(self, out, x, t):
+        x0 = out if self.objective == "pred_x0" else self.predict_start_from_noise(x, t, out)
+        return x0.clamp(-1.0, 1.0)
+
+    @torch.no_grad()
+    def _probe_precisions(self, candidates, sd=None, probe=None):
+        """The x0 predictions of each int8 precision in `candidates` against split-bf16's (which is within ~3e-5 of the fp32
+        reference on every checkpoint measured) on a probe batch: four windows of `seq_len` frames at
+        t = 999 (pure noise), t = 0 (x0-like samples: a 10-step deterministic DDIM chain of the split-bf16 engine from that noise)
+        and t = 500 (those samples re-noised).  All draws come from a private seeded CPU generator: torch's global RNG state,
+        which sample() consumes in the reference's order, is untouched.  `probe` = (x, x_cond) measures on the caller's own
+        tensors at t = 0 instead (the runtime guard).  Returns ({precision: max error}, [row maxima per LayerNorm site of the first
+        candidate's probe run])."""
+        dev = self.betas.device
+        d = self.denoise_fn
+        cfg = dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k, d_v=d.d_v,
+                   max_timesteps=d.max_timesteps, num_timesteps=int(self.betas.shape[0]), objective=self.objective)
+        sd = self.state_dict() if sd is None else sd
+        S = int(self.betas.shape[0])
+        ref = HipEngine(cfg, sd, dev, _lib.PREC_BF16X3, _lib.FLAG_NO_GRAPH)
+        try:
+            if probe is None:
+                B, T = 4, self.seq_len
+                g = torch.Generator().manual_seed(20260401)
+                xT = torch.randn((B, T, d.d_feats), generator=g).to(dev)
+                xc = torch.randn((B, T, d.d_feats), generator=g).to(dev)
+                eps = torch.randn((B, T, d.d_feats), generator=g).to(dev)
+                x0 = xT.clone()
+                ts = sorted({int(round(v)) for v in np.linspace(0, S - 1, min(10, S))}, reverse=True)
+                ref.ddim_loop_(x0, xc, ts)
+                cases = [(S - 1, xT), (0, x0)]
+                if S > 2:
+                    tm = torch.full((B,), S // 2, device=dev, dtype=torch.long)
+                    cases.append((S // 2, self.q_sample(x0, tm, eps).contiguous()))
+            else:
+                x, xc = probe
+                B, T = x.shape[0], x.shape[1]
+                cases = [(0, x)]
+            # what is compared: the clamped x0 prediction (what enters the posterior, M:235-246) in absolute terms, and the raw
+            # denoiser output relative to max(1, |y|max) (the `denoise` / `p_mean_variance(clip_denoised=False)` surface)
+            want = []
+            for tv, x in cases:
+                t = torch.full((B,), tv, device=dev, dtype=torch.long)
+                raw = ref.denoise(x, xc, t)
+                want.append((self._x0_from_output(raw, x, t), raw, max(1.0, float(raw.abs().max()))))
+            errors, row_max = {}, None
+            for prec in candidates:
+                eng = HipEngine(cfg, sd, dev, prec, _lib.FLAG_NO_GRAPH)
+                try:
+                    err = 0.0
+                    for (tv, x), (w0, wraw, wmax) in zip(cases, want):
+                        t = torch.full((B,), tv, device=dev, dtype=torch.long)
+                        raw = eng.denoise(x, xc, t)
+                        err = max(err, float((self._x0_from_output(raw, x, t) - w0).abs().max()), float((raw - wraw).abs().max()) / wmax)
+                    errors[prec] = err
+                    if row_max is None:
+                        row_max = eng.outlier_stats(B, T)
+                finally:
+                    eng.close()
+            return errors, row_max
+        finally:
+            ref.close()
 
     def _resolve_precision(self):
-        """The int8-slice precisions keep one scale per row (16-bit fixed point): LayerNorm gains far above the rest cost every
-        other feature of a row that many bits.  Measured: with DIFFERENT features amplified in each LayerNorm
-        (tools/hostile_weights_check.py) 8x gains stay inside the 1e-3 bar in every precision; with the SAME six features
-        amplified in all of them (tools/gain_sweep.py — their outliers compound through the residual stream) precisions 9 and 8
-        alike leave it at 5x (1.3e-3 / 1.2e-3 of |y|max; 5e-4 at 4x) while precision 3 stays below 2.5e-4 up to 25x.  Checked
-        once per weight (re)pack (one host sync): `hip_precision = "auto"` steps down to 3 above a max / median gain of 4; an
-        explicit int8 precision is kept and warned about."""
+        """Which operand precision the HIP context is built with.  The int8-slice precisions keep ONE scale per activation row (16-bit
+        fixed point): what they lose depends on the checkpoint (LayerNorm gains and shifts, massive activations, heavy-tailed
+        projections: DESIGN.md 3c), so `hip_precision = "auto"` MEASURES it on every (re)pack (`_probe_precisions`, a few
+        milliseconds): precision 9 if its probe error is within PROBE_LIMIT, else 8 if that is, else 3 with a RuntimeWarning.  An
+        explicit int8 precision is kept and warned about when its probe error exceeds the limit.  The outcome is in
+        `hip_precision_used` / `hip_precision_probe`."""
         want = self.hip_precision
+        self._slot.envelope = None
         if want != "auto" and want not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
+            self.hip_precision_probe = None
             return want
-        worst = 0.0
-        for name, p in self.denoise_fn.named_parameters():
-            if name.endswith("layer_norm.weight") and p.numel() > 1:
-                a = p.detach().abs().float()
-                worst = max(worst, float(a.max() / a.median().clamp_min(1e-12)))
-        if worst <= self.GAIN_SPREAD_LIMIT:
+        if want == "auto" and self._slot.demoted:
+            return _lib.PREC_BF16X3
+        if not self.hip_probe_at_pack:
+            self.hip_precision_probe = None
             return _lib.PREC_I8X3_FC if want == "auto" else want
+        cands = (_lib.PREC_I8X3_FC, _lib.PREC_I8X3) if want == "auto" else (want,)
+        errors, row_max = {}, None
+        pick = None
+        for prec in cands:  # (one at a time: the second candidate is only measured when the first fails)
+            e, rm = self._probe_precisions((prec,))
+            errors.update(e)
+            if e[prec] <= self.PROBE_LIMIT:
+                pick, row_max = prec, rm
+                break
+        self.hip_precision_probe = {"errors": errors, "limit": self.PROBE_LIMIT, "row_max": row_max}
+        if pick is not None:
+            self._slot.envelope = row_max
+            return pick
+        shown = ", ".join(f"precision {p}: {e:.1e}" for p, e in errors.items())
         if want == "auto":
             warnings.warn(
-                f"LayerNorm gains span a factor of {worst:.0f} (max / median): hip_precision='auto' falls back from the int8-slice "
-                f"default (9) to split-bf16 (3) for this checkpoint (~85 % more time per step); tools/precision_compare.py "
-                f"measures what each precision loses on it", RuntimeWarning, stacklevel=4)
+                f"hip_precision='auto': the int8-slice precisions differ from split-bf16 by more than {self.PROBE_LIMIT:.0e} on the probe "
+                f"batch for this checkpoint ({shown}); falling back to split-bf16 (3), ~85 % more time per step "
+                f"(tools/precision_compare.py measures each precision on it)", RuntimeWarning, stacklevel=4)
             return _lib.PREC_BF16X3
         warnings.warn(
-            f"LayerNorm gains span a factor of {worst:.0f} (max / median): hip_precision={want} keeps one int8-slice scale per row "
-            f"and may leave the 1e-3 bar on such a checkpoint; compare with tools/precision_compare.py or set "
-            f"model.hip_precision = {_lib.PREC_BF16X3} (or 'auto')", RuntimeWarning, stacklevel=4)
+            f"hip_precision={want} differs from split-bf16 by {errors[want]:.1e} on the probe batch for this checkpoint (limit "
+            f"{self.PROBE_LIMIT:.0e} of the 1e-3 bar): it may leave the bar; set model.hip_precision = 'auto' or {_lib.PREC_BF16X3}",
+            RuntimeWarning, stacklevel=4)
         return want
+
+    @torch.no_grad()
+    def _outlier_guard(self, eng, x, x_cond):
+        """End of a chain in an int8 precision: read the LayerNorm row maxima the chain produced (one stream sync).  Inside the
+        envelope the pack-time probe validated (x ENVELOPE_MARGIN) nothing else happens.  Beyond it the probe is repeated on the
+        chain's OWN tensors (its final x at t = 0): within PROBE_LIMIT the envelope grows to what was seen; outside it a
+        RuntimeWarning says so and `hip_precision = "auto"` steps down to split-bf16 from the next call on (this chain's result
+        stands: it is what was measured)."""
+        if not self.hip_outlier_guard or self.hip_precision_used not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC) or x.shape[0] == 0:
+            return
+        seen = eng.outlier_stats(x.shape[0], x.shape[1], reset=True)
+        self.hip_outlier_seen = seen
+        env = self._slot.envelope
+        lim = [self.ENVELOPE_ABSOLUTE] * len(seen) if env is None else [self.ENVELOPE_MARGIN * max(v, 1e-30) for v in env]
+        if all(s <= l for s, l in zip(seen, lim)):
+            return
+        prec = self.hip_precision_used
+        n = min(int(x.shape[0]), 8)
+        errors, _ = self._probe_precisions((prec,), probe=(x[:n].contiguous(), x_cond[:n].contiguous()))
+        if errors[prec] <= self.PROBE_LIMIT:
+            self._slot.envelope = [max(a, b) for a, b in zip(seen, env)] if env is not None else list(seen)
+            return
+        worst = max(range(len(seen)), key=lambda i: seen[i] / lim[i])
+        msg = (f"LayerNorm rows of this chain peak at {seen[worst]:.1f} (layer {worst // 2}, "
+               f"{'self_attn' if worst % 2 == 0 else 'pos_ffn'}.layer_norm), beyond what the pack-time probe validated, and precision "
+               f"{prec} differs from split-bf16 by {errors[prec]:.1e} on this chain's own tensors (limit {self.PROBE_LIMIT:.0e})")
+        if self.hip_precision == "auto":
+            self._slot.demoted = self._slot.force_repack = True  # re-pack at the next call
+            warnings.warn(msg + ": hip_precision='auto' uses split-bf16 (3) from the next call on", RuntimeWarning, stacklevel=4)
+        else:
+            warnings.warn(msg + f": hip_precision={prec} was set explicitly and is kept", RuntimeWarning, stacklevel=4)
 
     def _check_t(self, t):
         """The reference indexes its schedule buffers with t (`extract`, M:36-39) and the time embedding accepts any
@@ -409,6 +538,7 @@ class CondGaussianDiffusion(nn.Module):
             self._torch_rng_chain(eng, x, x_cond, S, pfx, padding_mask)
         else:
             raise ValueError(f"unknown sampling_rng {self.sampling_rng}")
+        self._outlier_guard(eng, x, x_cond)
         return x
 
     def _torch_rng_chain(self, eng, x, x_cond, S, prefix=None, padding_mask=None):
@@ -452,6 +582,7 @@ class CondGaussianDiffusion(nn.Module):
         x_cond = self._f32c(x_start * (1.0 - cond_mask) + cond_mask * cn)
         ts = sorted({int(round(v)) for v in np.linspace(0, self.num_timesteps - 1, n_steps)}, reverse=True)
         eng.ddim_loop_(x, x_cond, ts, eta=eta, seed=self.philox_seed)
+        self._outlier_guard(eng, x, x_cond)
         return x
 
     # ------------------------------------------------------------------ sliding-window harness (harness.py)
@@ -468,11 +599,12 @@ class CondGaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def sample_sliding_window_w_canonical(self, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None,
-                                          parents=None):
-        """`parents` (or `ds.parents`) overrides the SMPL-H kintree the conversion chain walks (SURVEY.md §8f #1)."""
+                                          parents=None, window_offset=0):
+        """`parents` (or `ds.parents`) overrides the SMPL-H kintree the conversion chain walks;
+        `window_offset`: global index of sequence 0 (dist.harness_sharded)."""
         from . import harness
         return harness.sample_sliding_window_w_canonical(self, ds, global_head_jpos, global_head_jquat, x_start, cond_mask,
-                                                         noise=noise, parents=parents)
+                                                         noise=noise, parents=parents, window_offset=window_offset)
 
     # ------------------------------------------------------------------ training half (plain PyTorch)
     def q_sample(self, x_start, t, noise=None):

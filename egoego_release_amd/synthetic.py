@@ -8,6 +8,7 @@ egoego/model/transformer_module.py:36-186 define the tensors and their init
 scales).  Values come from numpy's PCG64 keyed by (seed, tensor name), so the
 same state dict can be rebuilt anywhere without shipping 44 MB of weights.
 """
+import math
 import zlib
 
 import numpy as np
@@ -113,3 +114,64 @@ def make_head_windows(B, T, seed=0, d_feats=198):
     x[..., 156:159], x[..., 159:162] = r0, r1
     xs = torch.from_numpy(x)
     return xs, head_condition_mask(xs.shape)
+
+
+# ------------------------------------------------------------------------------------------ synthetic motion (training-like data)
+# first 22 entries of the SMPL-H kintree (harness.SMPLH_PARENTS_22)
+_PARENTS_22 = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19)
+
+
+def make_motion_windows(B, T, seed=0, device="cpu", d_feats=198):
+    """Seeded synthetic full-body windows in the model's data layout: [B, T, 198] = 22 normalised
+    global joint positions + 22 global rotations as 6D.  NOT real motion — the reference's AMASS data cannot ship — but it has
+    the structure a denoiser can learn from: a fixed seeded skeleton driven through forward kinematics by smooth per-joint
+    rotations (a few low-frequency sinusoids per axis) on a smooth root walk, the head at the xy origin in the first frame
+    like the reference's canonicalised windows (lafan1/utils.py:111-137), positions min/max-normalised to about [-1, 1] and 6D =
+    the first two rows of each global rotation (amass_diffusion_dataset.py:446-447).  Used to optimise the module's own training
+    loss for a few thousand steps (tools/make_trained_like_checkpoint.py): weights that are no longer the initialisation."""
+    assert d_feats == 198
+    dev = torch.device(device)
+    g = torch.Generator(device="cpu").manual_seed(int(seed) * 7919 + 13)
+    sk = np.random.Generator(np.random.PCG64([1234, 22]))  # the skeleton is the same for every seed
+    offs = sk.standard_normal((22, 3))
+    offs = offs / np.linalg.norm(offs, axis=1, keepdims=True) * sk.uniform(0.08, 0.35, (22, 1))
+    offs[0] = 0.0
+    offs = torch.from_numpy(offs.astype(np.float32)).to(dev)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(dev)
+
+    def uni(*shape):
+        return torch.rand(*shape, generator=g).to(dev)
+
+    tt = torch.arange(T, device=dev, dtype=torch.float32) / max(T, 1)
+    freqs = torch.tensor([0.5, 1.0, 2.0], device=dev)
+    amp = 0.35 * rnd(B, 22, 3, 3) / freqs                                         # [B, joint, axis, harmonic]
+    ph = 2 * math.pi * uni(B, 22, 3, 3)
+    aa = (amp[..., None] * torch.sin(2 * math.pi * freqs[:, None] * tt + ph[..., None])).sum(-2)  # [B, 22, 3, T]
+    aa = aa.permute(0, 3, 1, 2).contiguous()                                      # [B, T, 22, 3]
+    aa[:, :, 0, 2] += 2 * math.pi * uni(B, 1)                                      # random heading of the root
+    ang = aa.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+    ax = aa / ang
+    K = torch.zeros(B, T, 22, 3, 3, device=dev)
+    K[..., 0, 1], K[..., 0, 2], K[..., 1, 0] = -ax[..., 2], ax[..., 1], ax[..., 2]
+    K[..., 1, 2], K[..., 2, 0], K[..., 2, 1] = -ax[..., 0], -ax[..., 1], ax[..., 0]
+    eye = torch.eye(3, device=dev).expand(B, T, 22, 3, 3)
+    Rl = eye + torch.sin(ang)[..., None] * K + (1 - torch.cos(ang))[..., None] * (K @ K)  # Rodrigues
+    step = 0.01 * rnd(B, T, 3)
+    step = torch.nn.functional.avg_pool1d(step.transpose(1, 2), 9, 1, 4, count_include_pad=False).transpose(1, 2)
+    root = torch.cumsum(step, dim=1) * 3.0
+    root[..., 2] = 0.9 + 0.05 * torch.sin(2 * math.pi * (tt[None] + uni(B, 1)))
+    Rg, pos = [Rl[:, :, 0]], [root]
+    for j in range(1, 22):
+        p = _PARENTS_22[j]
+        Rg.append(Rg[p] @ Rl[:, :, j])
+        pos.append(pos[p] + (Rg[p] @ offs[j][None, None, :, None])[..., 0])
+    Rg, pos = torch.stack(Rg, 2), torch.stack(pos, 2)                               # [B, T, 22, 3, 3], [B, T, 22, 3]
+    shift = pos[:, :1, 15:16, :].clone()
+    shift[..., 2] = 0
+    pos = pos - shift
+    lo = torch.tensor([-1.5, -1.5, 0.0], device=dev)
+    hi = torch.tensor([1.5, 1.5, 2.0], device=dev)
+    pos = ((pos - lo) / (hi - lo) * 2 - 1).clamp(-1, 1)
+    return torch.cat((pos.reshape(B, T, 66), Rg[..., :2, :].reshape(B, T, 132)), -1).float()

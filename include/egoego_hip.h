@@ -16,7 +16,7 @@
  *   - synchronisation: the SAMPLING entry points (egoego_denoise, _p_sample, _sample_loop, _ddim_loop,
  *     _rot6d_to_matrix, _convert_model_res, _window_condition, _window_prefix, _debug_stage) only enqueue
  *     work and return; they never wait for the stream.  (egoego_ddim_loop stages its step table in a pinned
- *     slot and waits, at most, for the copy of the call four calls earlier; egoego_sample_loop drains the stream
+ *     slot and waits, at most, for the copy of the call four calls earlier; egoego_sample_loop drains the DEVICE
  *     once if a context has seen more than eight distinct step shapes and must evict a captured graph.)
  *     The SETUP entry points egoego_load_weights and egoego_load_schedule DO call hipStreamSynchronize(stream)
  *     (host staging buffers; a re-load first waits for work that still reads the old weights), and
@@ -29,7 +29,10 @@
  *   - pose tensors are fp32, contiguous, [B][T][d_feats]; timesteps are int64 [B] (torch.long).
  *   - return value: 0 = ok; negative = error (EGOEGO_E_*); egoego_last_error() describes the last
  *     failure on the calling thread.
- *   - one context per device; a context is not thread-safe.
+ *   - one context per device; a context is not thread-safe.  A context and each workspace are SINGLE-STREAM objects: the
+ *     captured step graphs are shared by every call of a shape, and the per-workspace step state (timestep counters, the
+ *     caller's buffer pointers, the Philox key) is rewritten by every loop call — two streams driving one workspace or one
+ *     context concurrently race silently.  Use one context + workspace per stream.
  */
 #ifndef EGOEGO_HIP_H
 #define EGOEGO_HIP_H
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-#define EGOEGO_ABI_VERSION 3
+#define EGOEGO_ABI_VERSION 4
 
 enum {
     EGOEGO_OK = 0,
@@ -214,6 +217,22 @@ enum { EGOEGO_K_QKV = 0, EGOEGO_K_ATTN = 1, EGOEGO_K_FC_LN = 2, EGOEGO_K_FFN1 = 
        EGOEGO_K_EMBED = 5, EGOEGO_K_OUT = 6, EGOEGO_K_COUNT = 7 };
 int egoego_profile_begin(egoego_ctx* ctx, int kernel_id);
 int egoego_profile_end(egoego_ctx* ctx, double* mean_us, int* launches);
+/* The kernel variant the launch site `kernel_id` of a step last dispatched to in this context (the library picks tile shapes and
+ * fused / split forms by batch size, window length and precision): e.g. "attn_layer_i8w_kernel", "tail_kernel<1,true,true,true,4,true>".
+ * "" before the first step.  What bench.py names its roofline kernels from (no dispatch logic outside the library). */
+const char* egoego_last_kernel_name(const egoego_ctx* ctx, int kernel_id);
+
+/* Outlier monitor of the int8-slice precisions (8, 9).  Those keep ONE scale per activation row (16-bit fixed point): a row whose
+ * largest entry is far above the rest costs every other entry of the row that many bits.  Every LayerNorm epilogue that
+ * quantises its rows records the largest |value| it has seen (one atomicMax per workgroup into the workspace's step state; nothing
+ * is recorded in precisions 3 / 1, for layers >= 8, or for the padding rows of the last token block).
+ * host_out[2 * layer + k] (k = 0: self_attn.layer_norm, k = 1: pos_ffn.layer_norm; n_out <= 16 entries, 0 = nothing recorded)
+ * receives the maxima accumulated by every call on this workspace since the last reset; reset != 0 clears them afterwards.
+ * Divide by the rms of the LayerNorm's (gain, bias) to get the row's crest factor — what model.py's runtime guard compares
+ * with its measured limit.  SYNCHRONISES `stream` when n_out > 0.  A freshly allocated workspace holds
+ * undefined values: call once with n_out = 0, reset = 1 (engine.py does) before relying on the maxima. */
+int egoego_outlier_stats(egoego_ctx* ctx, int B, int T, void* d_workspace, size_t workspace_bytes, float* host_out, int n_out,
+                         int reset, void* stream);
 
 /* Test/debug only: run the denoiser up to and including `stage` of decoder layer `layer` and
  * return that intermediate as fp32 row-major.  Stages: EGOEGO_DBG_*.  Output shapes:

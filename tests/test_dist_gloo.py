@@ -123,3 +123,96 @@ def test_rccl_init_and_all_gather_execute_with_one_rank():
     line = _json_line(r.stdout)
     assert line["rccl_ranks"] == 1 and line["collective_backend"] == "nccl" and line["gather_ms"] is not None
     assert line["output_finite"] and line["n_gpus"] == 1
+
+
+# ------------------------------------------------------------------------------------------ sequence-sharded harness
+class _StubModel:
+    """What dist.harness_sharded reads from the module when a stand-in harness runs: the window length and a device."""
+    seq_len = 20
+    betas = torch.zeros(1)
+
+
+def _fake_harness(hp, nz, off):
+    """Stand-in for the sliding-window harness: depends on the head pose, the sliced initial draws and the GLOBAL pair index only
+    (like the Philox-keyed HIP harness).  Returns (aa [b, T', 22, 3], root [b, T', 3]) with T' = harness.output_frames."""
+    from egoego_release_amd import harness
+    b, t = hp.shape[0], hp.shape[1]
+    t_out = harness.output_frames(t, _StubModel.seq_len)
+    idx = torch.arange(off, off + b, dtype=torch.float32)[:, None, None]
+    base = hp[:, :t_out, :3] + nz["x_all"][:, :t_out, :3] + sum(c[:, :1, :3] for c in nz["cond"]) + idx
+    return base[:, :, None, :].repeat(1, 1, 22, 1) * torch.arange(1, 23)[None, None, :, None], base * 2.0
+
+
+def _harness_worker(rank, world, port, n_seq, sample_bs, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hp = torch.randn(n_seq, 47, 7, generator=torch.Generator().manual_seed(4))
+    aa, root = D.harness_sharded(_StubModel(), None, hp, sample_bs=sample_bs, seed=9, harness_fn=_fake_harness)
+    if rank == 0:
+        torch.save((aa, root), out)
+    dist.destroy_process_group()
+
+
+def test_harness_sharded_by_sequence_two_gloo_ranks_match_one_process(tmp_path):
+    """the sliding-window harness shards over sequences x sample_bs, never over the windows of one sequence.  Two
+    gloo ranks with a stand-in harness: the gathered (aa, root) equals the single-process result for even and ragged splits and
+    for fewer pairs than ranks; the pair order is sequence-major (run_egoego.py:146's repeat)."""
+    from egoego_release_amd import harness
+    assert harness.window_spans(47, 20) == [(0, 20), (10, 20), (20, 20), (30, 17)] and harness.output_frames(47, 20) == 47
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for n_seq, sample_bs in ((4, 1), (3, 1), (1, 3), (1, 1)):
+        out = str(tmp_path / f"h{n_seq}_{sample_bs}.pt")
+        mp.spawn(_harness_worker, args=(2, port, n_seq, sample_bs, out), nprocs=2, join=True)
+        hp = torch.randn(n_seq, 47, 7, generator=torch.Generator().manual_seed(4))
+        want = D.harness_sharded(_StubModel(), None, hp, sample_bs=sample_bs, seed=9, harness_fn=_fake_harness)  # no process group: one rank
+        aa, root = torch.load(out)
+        assert aa.shape == (n_seq * sample_bs, 47, 22, 3) and root.shape == (n_seq * sample_bs, 47, 3)
+        assert torch.equal(aa, want[0]) and torch.equal(root, want[1])
+        if sample_bs > 1:  # the samples of one sequence share the head pose and differ in their draws / pair index
+            assert not torch.equal(aa[0], aa[1])
+
+
+@pytest.mark.gpu
+def test_harness_sharded_two_ranks_on_one_gpu_match_one_rank_bit_for_bit(tmp_path):
+    """The real harness through tools/run_stage2_demo.py --gpus N: the reference's 140-frame demo head trajectory replicated 4x
+    (two windows each: 120 + 30 frames), sharded by sequence over two gloo ranks that share the test box's GPU, against the
+    one-rank run of the same command — bit for bit (initial draws sliced from one seeded generator, per-step Philox keyed by the
+    global sequence index), and sample_bs = 2 on two sequences (pairs 0..3, sequence-major)."""
+    import pickle
+    import subprocess
+    import sys
+
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hg = np.load(os.path.join(root, "tests", "golden", "harness_golden.npz"))
+    from test_harness_golden import REST_OFFSETS
+    np.save(tmp_path / "rest.npy", REST_OFFSETS)
+    with open(tmp_path / "stats.p", "wb") as f:
+        pickle.dump({"global_jpos_min": hg["stats_global_jpos_min"], "global_jpos_max": hg["stats_global_jpos_max"]}, f)
+    env = dict(os.environ, EGOEGO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+
+    def run(n_seq, sample_bs, gpus, tag):
+        hp = np.repeat(hg["demo_head_qpos"][None], n_seq, 0).copy()
+        hp[:, :, 0] += 0.05 * np.arange(n_seq)[:, None]  # (not four identical trajectories)
+        np.save(tmp_path / f"head{n_seq}.npy", hp)
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_stage2_demo.py"), "--head_pose", str(tmp_path / f"head{n_seq}.npy"),
+                            "--stats", str(tmp_path / "stats.p"), "--rest_offsets", str(tmp_path / "rest.npy"), "--diffusion_window", "120",
+                            "--diffusion_batch_size", str(sample_bs), "--timesteps", "4", "--seed", "5", "--gpus", str(gpus), "--out", out],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(out), _json_line(r.stdout)
+
+    one, rep1 = run(4, 1, 1, "one")
+    two, rep2 = run(4, 1, 2, "two")
+    assert rep1["ranks"] == 1 and rep2["ranks"] == 2 and rep2["samples"] == 4 and rep2["frames"] == 140
+    for k in ("local_aa", "root_trans", "global_jpos"):
+        assert one[k].shape[0] == 4 and np.isfinite(one[k]).all() and np.array_equal(one[k], two[k]), k
+    assert not np.array_equal(one["local_aa"][0], one["local_aa"][1])
+    a, _ = run(2, 2, 1, "bs_one")
+    b, _ = run(2, 2, 2, "bs_two")
+    assert a["local_aa"].shape == (4, 140, 22, 3) and np.array_equal(a["local_aa"], b["local_aa"]) and np.array_equal(a["root_trans"], b["root_trans"])

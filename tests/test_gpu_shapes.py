@@ -192,13 +192,15 @@ def test_pred_noise_objective_all_timesteps(prec):
         assert err < bound, (tval, err)
 
 
-@pytest.mark.parametrize("B,T", [(2048, 120), (1024, 196), (8192, 120), (4680, 196)])
-def test_large_batches_match_the_same_windows_in_small_runs(B, T):
+@pytest.mark.parametrize("B,T,prec", [(2048, 120, _lib.PREC_I8X3), (1024, 196, _lib.PREC_I8X3), (8192, 120, _lib.PREC_I8X3), (4680, 196, _lib.PREC_I8X3),
+                                      (2048, 120, _lib.PREC_I8X3_FC), (8192, 120, _lib.PREC_I8X3_FC), (4680, 196, _lib.PREC_I8X3_FC)])
+def test_large_batches_match_the_same_windows_in_small_runs(B, T, prec):
     """Beyond BASELINE's sizes (288 GB of HBM take thousands of windows per call): windows at both ends and across the middle
     of a 2048-window (T=120) / 1024-window (T=196) batch equal, bit for bit, the same windows run four at a time at their
     global offset — index arithmetic of every kernel at 262144 / 229376 padded rows and at the largest accepted calls
     (8192 windows at T=120 = 2^20 rows, ≈27 GB of workspace; 4680 at T=196) — and one of them is checked against the oracle.  Row counts above 2^20 per call are refused."""
-    cfg, sd, m = _model(T=T, precision=_lib.PREC_I8X3)
+    # (precision 9, the default, as well: its O8 / o_scale buffers and the 16-row packing of long windows beyond 256 windows)
+    cfg, sd, m = _model(T=T, precision=prec)
     eng = m.hip_engine()
     xs, cm = make_head_windows(8, T, seed=5)
     g = torch.Generator(device="cuda").manual_seed(9)

@@ -4,7 +4,7 @@
 Runs the oracle's 1000-step chain on B windows with the same noise, once exactly (fp32) and once per variant with the
 operands of selected GEMMs rounded, and prints the max-abs difference of the final poses.
 
-    python tests/experiments/operand_rounding.py [B] [steps]
+    python tools/experiments/operand_rounding.py [B] [steps]
 """
 import os
 import sys

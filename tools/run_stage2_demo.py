@@ -89,12 +89,55 @@ def parse_opt(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--noise", default="", help="torch-saved dict {'x_all','cond','steps'} of injected draws (harness.py "
                                                "p_sample_loop_sliding_window_w_canonical): reproducibility / parity runs")
+    p.add_argument("--gpus", type=int, default=0,
+                   help="N >= 1: shard the (trajectory, sample) pairs over N GPUs by SEQUENCE (egoego_release_amd.dist.harness_sharded: "
+                        "Philox draws keyed by the global pair index, one all_gather of the result; the output does not depend on N). "
+                        "N > 1 starts its own ranks (a child `python -m torch.distributed.run`); EGOEGO_DIST_BACKEND=gloo lets ranks share a GPU. "
+                        "0 (default): the single-process path with the reference's RNG order")
     p.add_argument("--out", default="stage2_out.npz")
     return p.parse_args(argv)
 
 
+def self_launch(n, argv):
+    """`--gpus N` outside a launcher: run this very command under torch.distributed.run in a CHILD process (never an exec)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        raise SystemExit(proc.returncode or 1)
+    return json.loads(lines[-1])
+
+
 def main(argv=None):
     opt = parse_opt(argv)
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(opt.gpus, sys.argv[1:] if argv is None else argv)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("EGOEGO_DIST_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and world > ndev:
+            raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, {ndev} visible (EGOEGO_DIST_BACKEND=gloo shares GPUs between ranks)")
+        opt.device = str(int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev))
+        torch.cuda.set_device(int(opt.device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", int(opt.device)))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", int(opt.device))
     stats = _load_any(opt.stats)
     rest = np.load(opt.rest_offsets)
@@ -116,26 +159,41 @@ def main(argv=None):
     model.sampling_rng = opt.sampling_rng
     model.philox_seed = opt.seed
 
-    head_pose = load_head_pose(opt.head_pose).repeat_interleave(opt.diffusion_batch_size, 0).to(dev)
     torch.manual_seed(opt.seed)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    noise = torch.load(opt.noise, map_location="cpu") if opt.noise else None
-    aa, root = harness.full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=noise)
+    if opt.gpus >= 1:
+        # sequence-sharded: every (trajectory, sample) pair stays on one rank (its windows depend on each other), one all_gather at the end
+        from egoego_release_amd import dist as D
+        head_pose = load_head_pose(opt.head_pose)
+        aa, root = D.harness_sharded(model, ds, head_pose, sample_bs=opt.diffusion_batch_size, seed=opt.seed, parents=parents)
+        head_pose = head_pose.repeat_interleave(opt.diffusion_batch_size, 0)
+    else:
+        head_pose = load_head_pose(opt.head_pose).repeat_interleave(opt.diffusion_batch_size, 0).to(dev)
+        noise = torch.load(opt.noise, map_location="cpu") if opt.noise else None
+        aa, root = harness.full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=noise)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return None
     # global joints through FK, as run_egoego.py:152-158 does with ds.fk_smpl
     b, t = aa.shape[:2]
     gq, gj = ds.fk_smpl(root.reshape(-1, 3), aa.reshape(-1, 22, 3))
     gj = gj.reshape(b, t, 22, 3)
     out = {"local_aa": aa.cpu().numpy(), "root_trans": root.cpu().numpy(), "global_jpos": gj.cpu().numpy()}
     rep = {"frames": int(t), "samples": int(b), "windows": len(range(0, head_pose.shape[1], opt.diffusion_window - harness.OVERLAP)),
-           "diffusion_steps": opt.timesteps, "seconds": round(el, 3), "checkpoint": info}
+           "diffusion_steps": opt.timesteps, "seconds": round(el, 3), "checkpoint": info, "ranks": world,
+           "sharding": "by sequence (dist.harness_sharded)" if opt.gpus >= 1 else None}
     if opt.gt_jpos:
         gt = np.load(opt.gt_jpos)
         rep["mpjpe_mm"] = [mpjpe_mm(gj[i, : gt.shape[0]].cpu(), gt[:t]) for i in range(b)]
     np.savez_compressed(opt.out, **out)
-    print(json.dumps(rep))
+    print(json.dumps(rep), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
     return rep
 
 
