@@ -26,7 +26,7 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False, perfdebug=False, defines=(), tag=""):
+def build(force=False, verbose=False, perfdebug=False, defines=(), tag="", variant=False):
     """Compile csrc/*.hip -> egoego_release_amd/libegoego_hip.so (gfx950 only).
 
     perfdebug=True builds tools/_build/libegoego_hip_perfdebug.so instead: the same sources with -DEGOEGO_PERFDEBUG (per-block
@@ -43,7 +43,8 @@ def build(force=False, verbose=False, perfdebug=False, defines=(), tag=""):
     # the same row computed by two tilings, e.g. a 32-window shard and the full batch, may differ in the last place)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-shared", "-fPIC", "-o", out]
     if perfdebug:
-        cmd += ["-DEGOEGO_PERFDEBUG"] + [f"-D{d}" for d in defines]
+        # (--variant: the PRODUCT flags plus the extra defines — an A/B build of one knob, without the trace code)
+        cmd += ([] if variant else ["-DEGOEGO_PERFDEBUG"]) + [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -52,6 +53,6 @@ def build(force=False, verbose=False, perfdebug=False, defines=(), tag=""):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, perfdebug="--perfdebug" in sys.argv,
+    print(build(force="--force" in sys.argv, verbose=True, perfdebug="--perfdebug" in sys.argv or "--variant" in sys.argv, variant="--variant" in sys.argv,
                 defines=[a[2:] for a in sys.argv if a.startswith("-D")],
                 tag=next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), "")))

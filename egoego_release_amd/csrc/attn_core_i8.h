@@ -231,8 +231,10 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     const bool tile_active = qt_raw < KT;
     const int qt = tile_active ? qt_raw : KT - 1;
     const bool active = tile_active && qt * 32 + col < a.Lr;  // per lane: the last query tile may reach beyond the window's rows
-    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)a.k8, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)a.v8, 0, 0x7fffffff, 0x00020000);
+    // (resources based at THIS (window, head)'s image, so that the 32-bit offsets — slice stride + a few hundred KiB — stay far below
+    // the 2^31 - 1 bytes a buffer resource can span whatever the batch)
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.k8 + (((size_t)bh * KT * 8) << 10)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.v8 + (((size_t)bh * 8 * KT) << 10)), 0, 0x7fffffff, 0x00020000);
     constexpr int NPIECE = KT * 8 / 4;  // 1-KiB pieces of a half image (both slices) per wave: KT*4 blocks x 2 slices / 4 waves
     // K image [kt][8 d blocks]: half `hh` = d blocks 4hh .. 4hh+3 of every key tile -> buffer layout [kt][4]
     auto dma_k_half = [&](int hh, int buf) {
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
         for (int n = 0; n < NPIECE; ++n) {
             const int pc = n * 4 + wave;
             const int s = pc / (KT * 4), blk = pc - s * KT * 4, kt = blk >> 2, i = blk & 3;
-            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((((size_t)bh * KT + kt) * 8 + 4 * hh + i) << 10);
+            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((kt * 8 + 4 * hh + i) << 10);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(kr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + s * HALF + (blk << 10)), 16,
                                                      lane * 16, src, 0, 0);
         }
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
         for (int n = 0; n < NPIECE; ++n) {
             const int pc = n * 4 + wave;
             const int s = pc / (KT * 4), blk = pc - s * KT * 4;
-            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((((size_t)bh * 8 + 4 * hh) * KT + blk) << 10);
+            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((4 * hh * KT + blk) << 10);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + s * HALF + (blk << 10)), 16,
                                                      lane * 16, src, 0, 0);
         }

@@ -813,6 +813,8 @@ struct EpiResLN {
     float* lds_scale;
     // optional: outlier monitor (common.h StepState::ln_max) — the largest row maximum this launch quantises, one atomicMax per workgroup
     unsigned* outlier;
+    float* outlier_park;  // ... or an LDS slot that receives the maximum instead (mid-kernel epilogues: an atomic in the vector-memory queue
+                          // would sit in front of the next contraction's counted waits; the kernel flushes the slot at its end)
     int outlier_rows;  // token tiles reaching beyond this row hold the padding of the last token block (uninitialised inputs): not recorded
     // rr: the residual as int8 rows in registers (instead of res / res8); keep: receives the int8 rows this call produces
     template <int FT, int TT, class ResR = NoRows, class KeepR = NoRows>
@@ -992,7 +994,7 @@ struct EpiResLN {
 #ifndef EGOEGO_NO_MONITOR
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);  // (after the stores: the monitor must not lengthen any live range above)
-            if (outlier && wf == 0) {
+            if ((outlier || outlier_park) && wf == 0) {
                 // the row maxima once more from LDS (nothing is kept live across the quantisation above; red3 stays intact until
                 // the next barrier); both half-waves hold the same 32 tokens
                 float omax = 0.f;
@@ -1005,7 +1007,10 @@ struct EpiResLN {
                 }
 #pragma unroll
                 for (int o = 16; o >= 1; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
-                if (lane == 0) atomicMax(outlier, __builtin_bit_cast(unsigned, omax));
+                if (lane == 0) {
+                    if (outlier_park) *outlier_park = omax;
+                    else atomicMax(outlier, __builtin_bit_cast(unsigned, omax));
+                }
             }
 #endif
         }

@@ -249,7 +249,12 @@ struct DirectGemm {
                          int tt0, int wave, int lane, Mark mark, int wtile0 = -1, Post post = Post{}) {
         const int wt0 = wtile0 >= 0 ? wtile0 : wave * FT;  // first weight row tile of this wave (default: FT consecutive tiles per wave)
         i32x4 wq[RING][NW];
-        const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4), ir = tail_make_rsrc(in, in_plane * 4);
+        // The activation resource starts at THIS workgroup's first row tile (64-bit address arithmetic on the scalar unit), so the
+        // 32-bit offsets below stay small whatever the batch: with the base at row 0 the second slice of the int8 attention output
+        // of the largest accepted call (2^20 rows x 1024 bytes) ends exactly at 2^31, one byte beyond the largest num_records a
+        // buffer resource can hold — its last lanes read zeros (round 4: test_large_batches...[8192-120-9]).
+        const tail_rsrc wr = tail_make_rsrc(w, w_plane * 4);
+        const tail_rsrc ir = tail_make_rsrc((const char*)in + (((size_t)tt0 * (size_t)K16) << 10), 0x7fffffffu);
         const unsigned wpb = (unsigned)(w_plane * 2), ipb = (unsigned)(in_plane * 2);
         const int NQ = REM2 ? K16 / 8 + 1 : K16 / 8;  // chunks, the last one 2 k-steps long with REM2
         auto w_offsets = [&](int kb, unsigned (&out)[NW]) {
@@ -263,7 +268,7 @@ struct DirectGemm {
             const int s = x / (8 * TT), j = (x >> 3) % TT;
             int kb = x & 7;
             if (REM2 && q == NQ - 1) kb &= 1;  // the short chunk has 2 k-blocks: the other pieces re-load them (the counted waits assume a fixed piece count)
-            const unsigned src = s * ipb + (unsigned)(((tt0 + j) * K16 + 8 * q + kb) << 10);
+            const unsigned src = s * ipb + (unsigned)((j * K16 + 8 * q + kb) << 10);
             char* dst = act + (q & 1) * CH_BYTES + s * CH_PLANE + ((j * 8 + kb) << 10);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ir, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, src, 0, 0);
         };
@@ -360,7 +365,7 @@ struct DirectGemm {
 // tensor goes to memory (2 x 33 MB written and read back per launch at B=256 otherwise), no s_waitcnt vmcnt(0) + LDS-DMA round trip
 // stands between a LayerNorm and the contraction behind it, and the next contraction's first weight fragments are fetched
 // before the epilogue that precedes it.  Same integers, same float operations: same bits as the memory round trip.
-static constexpr int TAIL_RES_BYTES = 256;  // two [32] row-scale vectors in LDS
+static constexpr int TAIL_RES_BYTES = 272;  // two [32] row-scale vectors in LDS + the parked LayerNorm-1 outlier maximum
 template <int TT, bool FFN8, bool FC8 = false, bool W2 = false, int NWV = 4, bool RES = false>
 __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_kernel(TailArgs a) {
     static_assert(!RES || (FFN8 && FC8 && TT == 1), "LDS-resident FFN operands: the all-int8 32-token tail");
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
     // epilogue structs carry the large-batch kernels' code; only the tokens-per-block template argument differs
     auto as_ln = [&](const EpiResLN<2, 4, 0>& e, int which = 0) {
         return EpiResLN<2, NWV, TOK>{e.bias, e.res, e.res_plane, e.gamma, e.beta, e.row_mask, e.out, e.out_plane, e.eps, e.q8, e.q8_plane, e.q8_scale, e.res8, e.res8_plane, e.res8_scale, nullptr, nullptr,
-                                     a.outlier ? a.outlier + which : nullptr, a.outlier_rows};
+                                     a.outlier ? a.outlier + which : nullptr, nullptr, a.outlier_rows};
     };
     // All-int8 build: the ten per-feature parameter vectors of the three epilogues (weight row scales, biases, LayerNorm gains
     // and shifts) are staged in LDS once per workgroup — the epilogues of a 32-token workgroup are load-latency chains, and an
@@ -467,6 +472,7 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
             auto e = as_ln(a.ln1);
             if (a.stop != 1) { e.q8 = nullptr; e.q8_scale = nullptr; }  // (debug tap 1: the LayerNorm-1 rows also go to memory, a.ln1.q8)
             e.lds_q8 = act; e.lds_scale = ls1;
+            if (e.outlier) { e.outlier = nullptr; e.outlier_park = ls2 + 32; }  // flushed at the end of the kernel (thread 0 wrote it)
             e.template run<FT, TT, NoRows, Rows8<FT>>(acc, wave * FT * 32, tok0, lane, wave, 0, red, nullptr, &h1);
         }
         if (a.stop == 1) return;
@@ -495,6 +501,7 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
             e.res8 = nullptr;
             e.template run<FT, TT, Rows8<FT>, NoRows>(acc, wave * FT * 32, tok0, lane, wave, 0, red, &h1, nullptr);
         }
+        if (a.outlier && threadIdx.x == 0) atomicMax(a.outlier, __builtin_bit_cast(unsigned, ls2[32]));  // LayerNorm-1's parked maximum
         EG_DBG(if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); })
         mark(6);
         return;

@@ -308,7 +308,8 @@ class CondGaussianDiffusion(nn.Module):
             self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
         return self._slot.engine
 
-    PROBE_LIMIT = 6e-4       # largest |x0(int8 slices) - x0(split-bf16)| on the probe forwards for which an int8 precision is picked (0.6 of the 1e-3 bar)
+    PROBE_LIMIT = 7e-4       # largest difference from split-bf16 on the probe (end of a chain + two forwards) for which an int8 precision is picked (0.7 of the 1e-3 bar)
+    PROBE_TAIL = 30          # ancestral steps of the probe's end-of-chain run
     ENVELOPE_MARGIN = 1.5    # the runtime guard re-measures when a LayerNorm row maximum exceeds this multiple of what the probe validated
     ENVELOPE_ABSOLUTE = 8.0  # ... or this value when no probe ran (rows of the reference's initialisation peak at 4-5)
 
@@ -318,13 +319,19 @@ class CondGaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def _probe_precisions(self, candidates, sd=None, probe=None):
-        """The x0 predictions of each int8 precision in `candidates` against split-bf16's (which is within ~3e-5 of the fp32
-        reference on every checkpoint measured) on a probe batch: four windows of `seq_len` frames at
-        t = 999 (pure noise), t = 0 (x0-like samples: a 10-step deterministic DDIM chain of the split-bf16 engine from that noise)
-        and t = 500 (those samples re-noised).  All draws come from a private seeded CPU generator: torch's global RNG state,
-        which sample() consumes in the reference's order, is untouched.  `probe` = (x, x_cond) measures on the caller's own
-        tensors at t = 0 instead (the runtime guard).  Returns ({precision: max error}, [row maxima per LayerNorm site of the first
-        candidate's probe run])."""
+        """Each int8 precision in `candidates` against split-bf16 (which is within ~3e-5 of the fp32 reference on every checkpoint
+        measured) on a probe batch of four windows of `seq_len` frames:
+          * the END OF THE CHAIN: x0-like samples (a 10-step deterministic DDIM chain of the split-bf16 engine from seeded noise),
+            re-noised to t = PROBE_TAIL - 1, then the last PROBE_TAIL ancestral steps with the same in-kernel Philox draws in both
+            precisions — the final poses are compared.  This is where a trained denoiser accumulates operand rounding: near t = 0 its
+            prediction follows x_t, so every step's error rides along (measured on the trained-like checkpoint: 5.8e-4 on one
+            forward, 9.7e-4 at the end of the chain; the initialisation's chain does not grow);
+          * single forwards at t = S - 1 (pure noise) and S / 2: the clamped x0 prediction in absolute terms and the raw denoiser
+            output relative to max(1, |y|max).
+        All draws come from a private seeded CPU generator / Philox key: torch's global RNG state, which sample() consumes in the
+        reference's order, is untouched.  `probe` = (x, x_cond) measures on the caller's own tensors instead (the runtime guard):
+        x is taken as the sample, re-noised and walked down the same way.  Returns ({precision: max error}, [row maxima per
+        LayerNorm site of the first candidate's probe run])."""
         dev = self.betas.device
         d = self.denoise_fn
         cfg = dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k, d_v=d.d_v,
@@ -333,23 +340,31 @@ class CondGaussianDiffusion(nn.Module):
         S = int(self.betas.shape[0])
         ref = HipEngine(cfg, sd, dev, _lib.PREC_BF16X3, _lib.FLAG_NO_GRAPH)
         try:
+            g = torch.Generator().manual_seed(20260401)
             if probe is None:
                 B, T = 4, self.seq_len
-                g = torch.Generator().manual_seed(20260401)
                 xT = torch.randn((B, T, d.d_feats), generator=g).to(dev)
                 xc = torch.randn((B, T, d.d_feats), generator=g).to(dev)
-                eps = torch.randn((B, T, d.d_feats), generator=g).to(dev)
                 x0 = xT.clone()
                 ts = sorted({int(round(v)) for v in np.linspace(0, S - 1, min(10, S))}, reverse=True)
                 ref.ddim_loop_(x0, xc, ts)
-                cases = [(S - 1, xT), (0, x0)]
-                if S > 2:
-                    tm = torch.full((B,), S // 2, device=dev, dtype=torch.long)
-                    cases.append((S // 2, self.q_sample(x0, tm, eps).contiguous()))
+                cases = [(S - 1, xT)]
             else:
-                x, xc = probe
-                B, T = x.shape[0], x.shape[1]
-                cases = [(0, x)]
+                x0, xc = probe
+                B, T = x0.shape[0], x0.shape[1]
+                cases = []
+            eps = torch.randn((B, T, d.d_feats), generator=g).to(dev)
+            if S > 2 and probe is None:
+                tm = torch.full((B,), S // 2, device=dev, dtype=torch.long)
+                cases.append((S // 2, self.q_sample(x0, tm, eps).contiguous()))
+            n_tail = min(self.PROBE_TAIL, S)
+            x_tail = self.q_sample(x0, torch.full((B,), n_tail - 1, device=dev, dtype=torch.long), eps).contiguous()
+
+            def tail_chain(eng):
+                x = x_tail.clone()
+                eng.sample_loop_(x, xc, n_tail - 1, n_tail, noise_mode=_lib.NOISE_PHILOX, seed=20260401)
+                return x
+            want_tail = tail_chain(ref)
             # what is compared: the clamped x0 prediction (what enters the posterior, M:235-246) in absolute terms, and the raw
             # denoiser output relative to max(1, |y|max) (the `denoise` / `p_mean_variance(clip_denoised=False)` surface)
             want = []
@@ -366,6 +381,7 @@ class CondGaussianDiffusion(nn.Module):
                         t = torch.full((B,), tv, device=dev, dtype=torch.long)
                         raw = eng.denoise(x, xc, t)
                         err = max(err, float((self._x0_from_output(raw, x, t) - w0).abs().max()), float((raw - wraw).abs().max()) / wmax)
+                    err = max(err, float((tail_chain(eng) - want_tail).abs().max()))
                     errors[prec] = err
                     if row_max is None:
                         row_max = eng.outlier_stats(B, T)

@@ -38,7 +38,9 @@ def _ref_noise(shape, S, seed=123):
 
 def test_stagewise_against_oracle(prec):
     B, T, H = 2, 120, 4
-    STAGE_TOL = 6e-4 if prec == _lib.PREC_I8X3_FC else globals()["STAGE_TOL"]  # int8 fc: one more 16-bit rounding per layer
+    # precision 9: the stops run the PRODUCT kernels and tap their int8 rows (one more 16-bit rounding per layer in fc, residuals rebuilt
+    # from int8 rows, and the tap itself is a row of 16-bit fixed point: values up to ~6 -> steps of 2e-4)
+    STAGE_TOL = 1e-3 if prec == _lib.PREC_I8X3_FC else globals()["STAGE_TOL"]
     cfg, sd, m = _model(T, precision=prec)
     eng = m.hip_engine()
     x_all = torch.randn(B, T, 396, generator=torch.Generator().manual_seed(1120))

@@ -224,3 +224,24 @@ def test_large_batches_match_the_same_windows_in_small_runs(B, T, prec):
     nb = (1 << 20) // Lp + 1
     with pytest.raises(_lib.EgoEgoHipError, match="split the batch"):
         eng.workspace(nb, T)
+
+
+def test_contexts_on_two_devices_when_visible():
+    """The dynamic-LDS opt-in of every launch site is per DEVICE (egoego_hip.hip DevOnce), not per process: a second context on
+    another GPU of the same process must launch the same kernels.  (Needs two visible GPUs; the round-end box has one.)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    cfg = ModelConfig(max_timesteps=121)
+    sd = make_weights(cfg, 0)
+    xs, cm = make_head_windows(2, 120, seed=4)
+    outs = []
+    for dev in ("cuda:0", "cuda:1"):
+        m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+        m.load_state_dict(sd, strict=False)
+        m.hip_precision = _lib.PREC_I8X3_FC
+        m = m.to(dev)
+        m.num_timesteps, m.sampling_rng = 3, "philox"
+        g = torch.Generator().manual_seed(1)
+        nz = {"x_T": torch.randn(xs.shape, generator=g), "cond": torch.randn(xs.shape, generator=g), "steps": torch.randn(3, *xs.shape, generator=g)}
+        outs.append(m.sample(xs.to(dev), cm.to(dev), noise=nz).cpu())
+    assert torch.equal(outs[0], outs[1])

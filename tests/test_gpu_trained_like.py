@@ -192,9 +192,9 @@ def test_guards_are_quiet_and_cheap_on_the_reference_initialisation():
         b2 = m.sample(xs.cuda(), cm.cuda())
         assert torch.equal(b1, b2)
     # the pack-time probe does not touch torch's global generators (sample() consumes them in the reference's order)
+    m2 = _build(sd)  # (constructing the module draws its initial weights from the global generator, like the reference's)
     torch.manual_seed(123)
     c0, g0 = torch.get_rng_state(), torch.cuda.get_rng_state()
-    m2 = _build(sd)
     m2.hip_engine()
     assert torch.equal(c0, torch.get_rng_state()) and torch.equal(g0, torch.cuda.get_rng_state())
     assert m2.hip_precision_probe["errors"][_lib.PREC_I8X3_FC] < m2.PROBE_LIMIT
