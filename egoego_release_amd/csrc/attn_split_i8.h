@@ -12,6 +12,7 @@
 // at these sizes).
 #pragma once
 #include "attn_layer_i8w.h"
+#include "attn_layer_i8h.h"
 
 struct AttnSplitBufs {
     int8_t* img;   // [B*H][3][64 KiB]: Q, K (token tile, d_k block), V^T (d_v tile, key block); slice 2 at +32 KiB inside each image
@@ -263,6 +264,175 @@ __global__ __launch_bounds__(256, 2) void attn_proj6_i8_kernel(AttnLayerArgs a, 
                 *(u32x4*)dst = s1;
                 *(u32x4*)(dst + AL_SLICE) = s2;
             }
+        }
+    }
+}
+
+// The projections as TWO eight-wave workgroups per (window, head), 1.5 projections each: part 0 = K_h (all 128 keys) + Q_h of tokens
+// 0..63, part 1 = V_h (all keys) + Q_h of tokens 64..127 — the halves attn_proj6_i8_kernel already cuts Q into.  For 22..32 windows
+// per GPU (the per-rank shard of the 8-GPU split of BASELINE configs[2]): 256 workgroups = ONE round of the chip, where the
+// three-workgroup form needs 1.5 rounds and the one-kernel form leaves half the CUs idle behind a 38-us serial chain.
+// Same configurations, same epilogue code per value, same images as the other split forms: same bits (round 4).
+__global__ __launch_bounds__(512, 2) void attn_proj2_i8_kernel(AttnLayerArgs a, AttnSplitBufs o) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;                     // [512] cross-wave maxima
+    float* p_ws = red + 512;                       // [2][256] weight row scales: the main projection (K or V), Q
+    float* p_b = p_ws + 512;                       // [2][256] biases
+    float* p_hs = p_b + 512;                       // [128] row scales of the window's int8 input rows
+    char* ring = smem + 8192;
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // both parts of all H heads of a window share an XCD
+    const int bhl = lid >> 1, part = lid & 1;
+    const int which = 1 + part;                                  // the full projection of this part: 1 = K, 2 = V
+    const int bh = bhl + a.bh0;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const int wf = wave & 3, wt = wave >> 2;
+    const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
+    {
+        const int HD = a.H * 256;
+        const int sel = threadIdx.x >> 8, f = threadIdx.x & 255;  // 0: the main projection, 1: Q
+        const int src = (sel ? 0 : which) * HD + h * 256 + f;
+        p_ws[threadIdx.x] = a.w_scale[src];
+        p_b[threadIdx.x] = a.bias[src];
+        if (threadIdx.x < 128) p_hs[threadIdx.x] = a.h_scale[b * 128 + threadIdx.x];
+    }  // visible after the first barrier of the main loop
+    int8_t* const img = o.img + ((size_t)bh * 3 + which) * 65536;
+    {
+        const int t0 = wt * 64, f0 = wf * 64;
+        if (which == 1) {
+            // ---- K_h: attn_proj_i8_kernel's Q / K branch
+            I8Acc q[2][2];
+            GemmBody<AW8K, NoEpi>::mainloop(g, a.H + h, b, ring, q);
+            float* const scales = o.sk + (size_t)bh * 128;
+            f32x16 v[2][2];
+            float amax[2] = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float sa = p_hs[t0 + j * 32 + col];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    i8_dequant(q[i][j], v[i][j], p_ws + f0 + i * 32 + 4 * hf, sa);
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 b4 = *(const float4*)(p_b + f0 + i * 32 + 8 * gq + 4 * hf);
+                        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            v[i][j][4 * gq + c] = (v[i][j][4 * gq + c] + bb[c]) * 1.0f;
+                            amax[j] = fmaxf(amax[j], fabsf(v[i][j][4 * gq + c]));
+                        }
+                    }
+                }
+                amax[j] = fmaxf(amax[j], __shfl_xor(amax[j], 32));
+                if (hf == 0) red[wf * 128 + t0 + j * 32 + col] = amax[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tok = t0 + j * 32 + col;
+                const float rmax = fmaxf(fmaxf(red[tok], red[128 + tok]), fmaxf(red[256 + tok], red[384 + tok]));
+                const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+                if (wf == 0 && hf == 0) scales[tok] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float t[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
+                    u32x4 s1, s2;
+                    quant16(t, inv, s1, s2);
+                    int8_t* dst = img + (((wt * 2 + j) * 8 + wf * 2 + i) << 10) + lane * 16;
+                    *(u32x4*)dst = s1;
+                    *(u32x4*)(dst + AL_SLICE) = s2;
+                }
+            }
+        } else {
+            // ---- V_h: attn_proj_i8_kernel's V branch
+            I8Acc q[2][2];
+            GemmBody<AW8V, NoEpi>::mainloop(g, 2 * a.H + h, b, ring, q);
+            f32x16 v[2][2];
+            float amax[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float sw = p_ws[f0 + i * 32 + col], bf = p_b[f0 + i * 32 + col];
+                amax[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    i8_dequant_rows(q[i][j], v[i][j], sw, p_hs + t0 + j * 32 + 4 * hf);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        v[i][j][r] += bf;
+                        amax[i] = fmaxf(amax[i], fabsf(v[i][j][r]));
+                    }
+                }
+                amax[i] = fmaxf(amax[i], __shfl_xor(amax[i], 32));
+                if (hf == 0) red[wt * 256 + wf * 64 + i * 32 + col] = amax[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int dv = wf * 64 + i * 32 + col;
+                const float cmax = fmaxf(red[dv], red[256 + dv]);
+                const float inv = cmax > 0.f ? I8_QMAX / cmax : 0.f;
+                if (wt == 0 && hf == 0) o.sv[(size_t)bh * 256 + dv] = cmax > 0.f ? cmax / I8_QMAX : 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float t[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = v[i][j][r];
+                    u32x4 s1, s2;
+                    quant16(t, inv, s1, s2);
+                    int8_t* dst = img + (((wf * 2 + i) * 4 + wt * 2 + j) << 10) + lane * 16;
+                    *(u32x4*)dst = s1;
+                    *(u32x4*)(dst + AL_SLICE) = s2;
+                }
+            }
+        }
+    }
+    // ---- Q_h of this part's 64 tokens: waves 4 (features) x 2 (token tiles), 64f x 32t per wave (attn_layer_i8h_kernel's phase 2),
+    // the image rows and scales to memory.  (The main loop's first barrier also separates the reads of `red` above from the writes below.)
+    {
+        const int qh = part;
+        I8Acc q[2][1];
+        GemmBody<AH8Q, NoEpi>::mainloop(g, h, b * 2 + qh, ring, q);
+        const int f0 = wf * 64;
+        const float* const q_ws = p_ws + 256;
+        const float* const q_b = p_b + 256;
+        f32x16 v[2];
+        float amax = 0.f;
+        const float sa = p_hs[qh * 64 + wt * 32 + col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            i8_dequant(q[i][0], v[i], q_ws + f0 + i * 32 + 4 * hf, sa);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 b4 = *(const float4*)(q_b + f0 + i * 32 + 8 * gq + 4 * hf);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[i][4 * gq + c] = (v[i][4 * gq + c] + bb[c]) * a.qscale;
+                    amax = fmaxf(amax, fabsf(v[i][4 * gq + c]));
+                }
+            }
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        if (hf == 0) red[wf * 64 + wt * 32 + col] = amax;
+        __syncthreads();
+        const int tl = wt * 32 + col, tok = qh * 64 + tl;
+        const float rmax = fmaxf(fmaxf(red[tl], red[64 + tl]), fmaxf(red[128 + tl], red[192 + tl]));
+        const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
+        if (wf == 0 && hf == 0) o.sq[(size_t)bh * 128 + tok] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
+        int8_t* const qimg = o.img + (size_t)bh * 3 * 65536;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = v[i][r];
+            u32x4 s1, s2;
+            quant16(t, inv, s1, s2);
+            int8_t* dst = qimg + (((qh * 2 + wt) * 8 + wf * 2 + i) << 10) + lane * 16;
+            *(u32x4*)dst = s1;
+            *(u32x4*)(dst + AL_SLICE) = s2;
         }
     }
 }

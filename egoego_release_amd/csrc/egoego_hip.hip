@@ -476,6 +476,11 @@ static int launch_tail_f(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_
 #ifndef ATTN_SPLIT6_MAX_BLOCKS
 #define ATTN_SPLIT6_MAX_BLOCKS 256
 #endif
+// ... and as TWO eight-wave workgroups per (window, head), 1.5 projections each, + the core launch for 22..32 windows (one round of
+// the chip where the three-workgroup form takes 1.5 and the one-kernel forms leave half of it idle)
+#ifndef ATTN_SPLIT2_MAX_BLOCKS
+#define ATTN_SPLIT2_MAX_BLOCKS 256
+#endif
 #ifndef ATTN_HALF_MAX_BLOCKS
 #define ATTN_HALF_MAX_BLOCKS 192
 #endif
@@ -683,6 +688,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 HIP_TRY(allow_smem(attn_proj_i8_kernel, ATTN_PROJ_SMEM));
                 HIP_TRY(allow_smem(attn_core_s_kernel, ATTN_CORE_S_SMEM));
                 HIP_TRY(allow_smem(attn_proj6_i8_kernel, ATTN_PROJ6_SMEM));
+                HIP_TRY(allow_smem(attn_proj2_i8_kernel, ATTN_PROJ_SMEM));
                 once.done();
             }
             // the projections as three workgroups per (window, head) + a core launch while they fit the chip at once (attn_split_i8.h);
@@ -697,6 +703,12 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 const AttnSplitBufs sb{w.att_img, w.sq8, w.sk8, (float*)w.V};
                 c->last_kernel[EGOEGO_K_QKV] = "attn_proj_i8_kernel";
                 attn_proj_i8_kernel<<<dim3(nw * H * 3), dim3(512), ATTN_PROJ_SMEM, s>>>(al, sb);
+                HIP_TRY(hipGetLastError());
+                attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
+            } else if (w.att_img && nw * H * 2 <= ATTN_SPLIT2_MAX_BLOCKS) {
+                const AttnSplitBufs sb{w.att_img, w.sq8, w.sk8, (float*)w.V};
+                c->last_kernel[EGOEGO_K_QKV] = "attn_proj2_i8_kernel";
+                attn_proj2_i8_kernel<<<dim3(nw * H * 2), dim3(512), ATTN_PROJ_SMEM, s>>>(al, sb);
                 HIP_TRY(hipGetLastError());
                 attn_core_s_kernel<<<dim3(nw * H), dim3(512), ATTN_CORE_S_SMEM, s>>>(al, sb);
             } else

@@ -17,9 +17,12 @@ def _f32c(t, device):
 
 
 class HipEngine:
-    def __init__(self, cfg_dict, state_dict, device, precision=_lib.PREC_I8X3_FC, flags=0):
+    def __init__(self, cfg_dict, state_dict, device, precision=_lib.PREC_I8X3_FC, flags=0, row_shift=None):
         """cfg_dict: d_feats, d_model, n_head, n_dec_layers, d_k, d_v, max_timesteps, num_timesteps,
-        objective ('pred_x0' | 'pred_noise').  state_dict: reference-layout tensors (any device)."""
+        objective ('pred_x0' | 'pred_noise').  state_dict: reference-layout tensors (any device).
+        row_shift: the per-feature constants a mean-shifted state dict (precision.prepare_int8_state) leaves out of the rows it
+        stores — {'embed' | (layer, 'attn_ln') | (layer, 'out'): [512]}; only the debug taps need them (added back there)."""
+        self.row_shift = row_shift or {}
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -204,6 +207,10 @@ class HipEngine:
         _lib.check(self.lib.egoego_debug_stage(self._ctx, self._chk(x), self._chk(x_cond, x.shape),
                                                self._chk(t, (B,), torch.int64), mp, layer, sid, out.data_ptr(), B, T,
                                                ws, n, self._stream()))
+        sh = self.row_shift.get("embed" if stage == "embed" else (layer, stage))
+        if sh is not None:
+            sh = sh.to(out.device, out.dtype)
+            out += sh.view(H, 1, 256) if stage in ("q", "k", "v") else sh
         return out
 
     def rot6d_to_matrix(self, d6):

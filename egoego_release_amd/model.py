@@ -23,6 +23,7 @@ from torch import nn
 
 from . import _lib
 from .engine import HipEngine
+from .precision import PrecisionProbe, prepare_int8_state, _engine_cfg
 from .synthetic import sinusoid_position_table
 
 
@@ -145,6 +146,8 @@ class _EngineSlot:
 
     def __init__(self):
         self.engine, self.key, self.fingerprint = None, None, None
+        self.engine_masked = None  # the context for padding-mask calls when the main one stores mean-shifted rows
+        self.plan = None       # what the context was packed from (_resolve_precision)
         self.ramp = None       # fingerprint weights (one per packed element)
         self.noise_buf = None  # scratch of the torch-RNG chain, reused across sample() calls
         self.envelope = None   # per LayerNorm site: the largest row maximum the pack-time probe has validated (runtime guard)
@@ -213,6 +216,7 @@ class CondGaussianDiffusion(nn.Module):
         self.hip_precision_used = None
         self.hip_precision_probe = None   # what the pack-time probe measured: {"errors": {9: .., 8: ..}, "limit": .., "row_max": [..]}
         self.hip_probe_at_pack = True     # False: skip the probe (auto = 9, absolute envelope for the runtime guard)
+        self.hip_int8_prep = "auto"       # pack-time preparation of int8 precisions (precision.py): "auto" = only when the plain packing fails the probe; "always"; "never"
         self.hip_outlier_guard = True     # False: no read-back (and no stream sync) at the end of a chain
         self.hip_outlier_seen = None      # per LayerNorm site, the largest row maximum of the last guarded chain
         self.hip_graph = True        # replay one captured step per chain (hipGraph); False launches every kernel
@@ -257,9 +261,11 @@ class CondGaussianDiffusion(nn.Module):
         """Drop the packed copy of the weights: the next sampling call re-packs from the module's current tensors.
         Called by load_state_dict / .to() / .cuda() / .half() etc.; call it yourself after writing weights through
         `.data` if you then use the per-step API (`p_sample`, `denoise`), which does not checksum."""
-        if self._slot.engine is not None:
-            self._slot.engine.close()
+        for e in (self._slot.engine, self._slot.engine_masked):
+            if e is not None:
+                e.close()
         self._slot.engine, self._slot.key, self._slot.fingerprint = None, None, None
+        self._slot.engine_masked, self._slot.plan = None, None
         self._slot.noise_buf = None
         self._slot.envelope, self._slot.demoted, self._slot.force_repack = None, False, False
 
@@ -274,11 +280,12 @@ class CondGaussianDiffusion(nn.Module):
             self.invalidate_engine()
         return out
 
-    def hip_engine(self, verify=False):
+    def hip_engine(self, verify=False, masked=False):
         """The HIP context for the module's current device/weights (packed lazily, re-packed when parameters change
         or the module moves).  verify=True (every chain-level entry point: sample, p_sample_loop, ddim_sample, the
         sliding-window harness) additionally compares a device-side checksum of the weights with the one taken when
-        they were packed."""
+        they were packed.  masked=True: the context for calls that carry a padding mask — the same precision, but packed without
+        the mean shift of the LayerNorm rows when the main context has it (precision.py: a mask zeroes rows AFTER the shift)."""
         dev = self.betas.device
         if dev.type != "cuda":
             raise _lib.EgoEgoHipError(
@@ -289,158 +296,108 @@ class CondGaussianDiffusion(nn.Module):
         stale = (self._slot.engine is None or self._slot.key != key or (verify and self._slot.fingerprint != fp)
                  or self._slot.force_repack)
         if stale:
-            if self._slot.engine is not None:
-                self._slot.engine.close()
-                self._slot.engine = None
+            for e in (self._slot.engine, self._slot.engine_masked):
+                if e is not None:
+                    e.close()
+            self._slot.engine = self._slot.engine_masked = None
             if not self._slot.force_repack:
                 self._slot.demoted = False  # new weights / device / settings: measured afresh
             self._slot.force_repack = False
-            d = self.denoise_fn
-            cfg = dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k,
-                       d_v=d.d_v, max_timesteps=d.max_timesteps, num_timesteps=int(self.betas.shape[0]),
-                       objective=self.objective)
             if self.objective not in ("pred_noise", "pred_x0"):
                 raise ValueError(f"unknown objective {self.objective}")
-            self.hip_precision_used = self._resolve_precision()
-            self._slot.engine = HipEngine(cfg, self.state_dict(), dev, self.hip_precision_used,
-                                          0 if self.hip_graph else _lib.FLAG_NO_GRAPH)
+            self._slot.plan = plan = self._resolve_precision()
+            self.hip_precision_used = plan["precision"]
+            self._slot.engine = HipEngine(_engine_cfg(self), plan["sd"] if plan["sd"] is not None else self.state_dict(), dev, plan["precision"],
+                                          0 if self.hip_graph else _lib.FLAG_NO_GRAPH, row_shift=plan["row_shift"])
             self._slot.key = key
             self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
+        if masked and self._slot.plan["row_shift"]:
+            if self._slot.engine_masked is None:
+                self._slot.engine_masked = HipEngine(_engine_cfg(self), self._slot.plan["sd_unshifted"], dev, self._slot.plan["precision"],
+                                                     0 if self.hip_graph else _lib.FLAG_NO_GRAPH)
+            return self._slot.engine_masked
         return self._slot.engine
 
-    PROBE_LIMIT = 7e-4       # largest difference from split-bf16 on the probe (end of a chain + two forwards) for which an int8 precision is picked (0.7 of the 1e-3 bar)
-    PROBE_TAIL = 30          # ancestral steps of the probe's end-of-chain run
+    PROBE_LIMIT = 5e-4       # largest difference from split-bf16 on the probe (end of a chain + two forwards) for which an int8 precision is
+                             # used: half the 1e-3 bar — a real chain on other data ran 1.5-1.7x its probe figure (trained-like checkpoint)
+    PROBE_TAIL = 50          # ancestral steps of the probe's end-of-chain run
     ENVELOPE_MARGIN = 1.5    # the runtime guard re-measures when a LayerNorm row maximum exceeds this multiple of what the probe validated
     ENVELOPE_ABSOLUTE = 8.0  # ... or this value when no probe ran (rows of the reference's initialisation peak at 4-5)
 
-    def _x0_from_output(self, out, x, t):
-        x0 = out if self.objective == "pred_x0" else self.predict_start_from_noise(x, t, out)
-        return x0.clamp(-1.0, 1.0)
-
-    @torch.no_grad()
-    def _probe_precisions(self, candidates, sd=None, probe=None):
-        """Each int8 precision in `candidates` against split-bf16 (which is within ~3e-5 of the fp32 reference on every checkpoint
-        measured) on a probe batch of four windows of `seq_len` frames:
-          * the END OF THE CHAIN: x0-like samples (a 10-step deterministic DDIM chain of the split-bf16 engine from seeded noise),
-            re-noised to t = PROBE_TAIL - 1, then the last PROBE_TAIL ancestral steps with the same in-kernel Philox draws in both
-            precisions — the final poses are compared.  This is where a trained denoiser accumulates operand rounding: near t = 0 its
-            prediction follows x_t, so every step's error rides along (measured on the trained-like checkpoint: 5.8e-4 on one
-            forward, 9.7e-4 at the end of the chain; the initialisation's chain does not grow);
-          * single forwards at t = S - 1 (pure noise) and S / 2: the clamped x0 prediction in absolute terms and the raw denoiser
-            output relative to max(1, |y|max).
-        All draws come from a private seeded CPU generator / Philox key: torch's global RNG state, which sample() consumes in the
-        reference's order, is untouched.  `probe` = (x, x_cond) measures on the caller's own tensors instead (the runtime guard):
-        x is taken as the sample, re-noised and walked down the same way.  Returns ({precision: max error}, [row maxima per
-        LayerNorm site of the first candidate's probe run])."""
-        dev = self.betas.device
-        d = self.denoise_fn
-        cfg = dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k, d_v=d.d_v,
-                   max_timesteps=d.max_timesteps, num_timesteps=int(self.betas.shape[0]), objective=self.objective)
-        sd = self.state_dict() if sd is None else sd
-        S = int(self.betas.shape[0])
-        ref = HipEngine(cfg, sd, dev, _lib.PREC_BF16X3, _lib.FLAG_NO_GRAPH)
-        try:
-            g = torch.Generator().manual_seed(20260401)
-            if probe is None:
-                B, T = 4, self.seq_len
-                xT = torch.randn((B, T, d.d_feats), generator=g).to(dev)
-                xc = torch.randn((B, T, d.d_feats), generator=g).to(dev)
-                x0 = xT.clone()
-                ts = sorted({int(round(v)) for v in np.linspace(0, S - 1, min(10, S))}, reverse=True)
-                ref.ddim_loop_(x0, xc, ts)
-                cases = [(S - 1, xT)]
-            else:
-                x0, xc = probe
-                B, T = x0.shape[0], x0.shape[1]
-                cases = []
-            eps = torch.randn((B, T, d.d_feats), generator=g).to(dev)
-            if S > 2 and probe is None:
-                tm = torch.full((B,), S // 2, device=dev, dtype=torch.long)
-                cases.append((S // 2, self.q_sample(x0, tm, eps).contiguous()))
-            n_tail = min(self.PROBE_TAIL, S)
-            x_tail = self.q_sample(x0, torch.full((B,), n_tail - 1, device=dev, dtype=torch.long), eps).contiguous()
-
-            def tail_chain(eng):
-                x = x_tail.clone()
-                eng.sample_loop_(x, xc, n_tail - 1, n_tail, noise_mode=_lib.NOISE_PHILOX, seed=20260401)
-                return x
-            want_tail = tail_chain(ref)
-            # what is compared: the clamped x0 prediction (what enters the posterior, M:235-246) in absolute terms, and the raw
-            # denoiser output relative to max(1, |y|max) (the `denoise` / `p_mean_variance(clip_denoised=False)` surface)
-            want = []
-            for tv, x in cases:
-                t = torch.full((B,), tv, device=dev, dtype=torch.long)
-                raw = ref.denoise(x, xc, t)
-                want.append((self._x0_from_output(raw, x, t), raw, max(1.0, float(raw.abs().max()))))
-            errors, row_max = {}, None
-            for prec in candidates:
-                eng = HipEngine(cfg, sd, dev, prec, _lib.FLAG_NO_GRAPH)
-                try:
-                    err = 0.0
-                    for (tv, x), (w0, wraw, wmax) in zip(cases, want):
-                        t = torch.full((B,), tv, device=dev, dtype=torch.long)
-                        raw = eng.denoise(x, xc, t)
-                        err = max(err, float((self._x0_from_output(raw, x, t) - w0).abs().max()), float((raw - wraw).abs().max()) / wmax)
-                    err = max(err, float((tail_chain(eng) - want_tail).abs().max()))
-                    errors[prec] = err
-                    if row_max is None:
-                        row_max = eng.outlier_stats(B, T)
-                finally:
-                    eng.close()
-            return errors, row_max
-        finally:
-            ref.close()
-
     def _resolve_precision(self):
-        """Which operand precision the HIP context is built with.  The int8-slice precisions keep ONE scale per activation row (16-bit
-        fixed point): what they lose depends on the checkpoint (LayerNorm gains and shifts, massive activations, heavy-tailed
-        projections: DESIGN.md 3c), so `hip_precision = "auto"` MEASURES it on every (re)pack (`_probe_precisions`, a few
-        milliseconds): precision 9 if its probe error is within PROBE_LIMIT, else 8 if that is, else 3 with a RuntimeWarning.  An
-        explicit int8 precision is kept and warned about when its probe error exceeds the limit.  The outcome is in
-        `hip_precision_used` / `hip_precision_probe`."""
+        """What the HIP context is packed from: {"precision", "sd" (None = the module's own state dict), "row_shift", "sd_unshifted",
+        "prepared"}.  The int8-slice precisions are 16-bit FIXED point (one scale per activation row / weight row); what they lose
+        depends on the checkpoint — on trained weights mostly the weight grid under a sharp attention and LayerNorm rows with a
+        near-constant massive feature (precision.py).  So nothing is assumed: `hip_precision = "auto"` MEASURES, on
+        every (re)pack, each candidate against split-bf16 on a probe batch (`PrecisionProbe.error`: the end of a chain + two
+        forwards) and takes the first one within PROBE_LIMIT of
+            9 as is  ->  9 prepared  ->  8 as is  ->  8 prepared  ->  3 (with a RuntimeWarning),
+        "prepared" = the pack-time transformations of precision.py (mean-shifted LayerNorm rows folded into biases, error-compensating
+        rounding of the int8 weights on the library's own grid: same kernels, same speed; ~1 s more packing, paid only when the plain
+        packing fails the probe; `hip_int8_prep` = "always" / "never" forces it on / off).  An explicit int8 precision is kept (prepared
+        if that is what passes) and warned about when neither form is within the limit.  The outcome is in `hip_precision_used` /
+        `hip_precision_probe`."""
         want = self.hip_precision
         self._slot.envelope = None
+        plain = {"precision": want, "sd": None, "row_shift": None, "sd_unshifted": None, "prepared": False}
         if want != "auto" and want not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
             self.hip_precision_probe = None
-            return want
+            return plain
         if want == "auto" and self._slot.demoted:
-            return _lib.PREC_BF16X3
+            return dict(plain, precision=_lib.PREC_BF16X3)
         if not self.hip_probe_at_pack:
             self.hip_precision_probe = None
-            return _lib.PREC_I8X3_FC if want == "auto" else want
+            return dict(plain, precision=_lib.PREC_I8X3_FC if want == "auto" else want)
         cands = (_lib.PREC_I8X3_FC, _lib.PREC_I8X3) if want == "auto" else (want,)
-        errors, row_max = {}, None
-        pick = None
-        for prec in cands:  # (one at a time: the second candidate is only measured when the first fails)
-            e, rm = self._probe_precisions((prec,))
-            errors.update(e)
-            if e[prec] <= self.PROBE_LIMIT:
-                pick, row_max = prec, rm
-                break
-        self.hip_precision_probe = {"errors": errors, "limit": self.PROBE_LIMIT, "row_max": row_max}
+        forms = {"auto": (False, True), "always": (True,), "never": (False,)}[self.hip_int8_prep]
+        probe = PrecisionProbe(self, tail=self.PROBE_TAIL)
+        errors, calib, pick = {}, None, None
+        try:
+            sd = probe.sd
+            for prec in cands:
+                for prepared in forms:
+                    if prepared:
+                        calib = probe.calibration() if calib is None else calib
+                        sd_s, row_shift = prepare_int8_state(sd, calib, prec, shift=True)
+                        # for padding-mask calls: the same rounded weights and K / V shifts, no LayerNorm-row shift (no second rounding pass)
+                        sd_u, _ = prepare_int8_state({k: (sd_s[k] if k.endswith(".weight") else v) for k, v in sd.items()}, calib, prec,
+                                                     shift=False, rounding=False)
+                    else:
+                        sd_s, row_shift, sd_u = sd, None, None
+                    err, row_max = probe.error(sd_s, prec, row_shift)
+                    errors[(prec, "prepared" if prepared else "as is")] = err
+                    if err <= self.PROBE_LIMIT:
+                        pick = {"precision": prec, "sd": sd_s if prepared else None, "row_shift": row_shift, "sd_unshifted": sd_u, "prepared": prepared}
+                        break
+                if pick is not None:
+                    break
+        finally:
+            probe.close()
+        self.hip_precision_probe = {"errors": {f"{p} {f}": e for (p, f), e in errors.items()}, "limit": self.PROBE_LIMIT,
+                                    "row_max": row_max if pick is not None else None, "prepared": bool(pick and pick["prepared"])}
         if pick is not None:
             self._slot.envelope = row_max
             return pick
-        shown = ", ".join(f"precision {p}: {e:.1e}" for p, e in errors.items())
+        shown = ", ".join(f"precision {p} {f}: {e:.1e}" for (p, f), e in errors.items())
         if want == "auto":
             warnings.warn(
                 f"hip_precision='auto': the int8-slice precisions differ from split-bf16 by more than {self.PROBE_LIMIT:.0e} on the probe "
                 f"batch for this checkpoint ({shown}); falling back to split-bf16 (3), ~85 % more time per step "
                 f"(tools/precision_compare.py measures each precision on it)", RuntimeWarning, stacklevel=4)
-            return _lib.PREC_BF16X3
+            return dict(plain, precision=_lib.PREC_BF16X3)
         warnings.warn(
-            f"hip_precision={want} differs from split-bf16 by {errors[want]:.1e} on the probe batch for this checkpoint (limit "
-            f"{self.PROBE_LIMIT:.0e} of the 1e-3 bar): it may leave the bar; set model.hip_precision = 'auto' or {_lib.PREC_BF16X3}",
+            f"hip_precision={want} differs from split-bf16 by more than {self.PROBE_LIMIT:.0e} on the probe batch for this checkpoint "
+            f"({shown}; the limit is half the 1e-3 bar): it may leave the bar; set model.hip_precision = 'auto' or {_lib.PREC_BF16X3}",
             RuntimeWarning, stacklevel=4)
-        return want
+        return plain
 
     @torch.no_grad()
     def _outlier_guard(self, eng, x, x_cond):
         """End of a chain in an int8 precision: read the LayerNorm row maxima the chain produced (one stream sync).  Inside the
         envelope the pack-time probe validated (x ENVELOPE_MARGIN) nothing else happens.  Beyond it the probe is repeated on the
-        chain's OWN tensors (its final x at t = 0): within PROBE_LIMIT the envelope grows to what was seen; outside it a
-        RuntimeWarning says so and `hip_precision = "auto"` steps down to split-bf16 from the next call on (this chain's result
-        stands: it is what was measured)."""
+        chain's OWN tensors (its final x re-noised and walked down again): within PROBE_LIMIT the envelope grows to what was seen;
+        outside it a RuntimeWarning says so and `hip_precision = "auto"` steps down to split-bf16 from the next call on (this
+        chain's result stands: it is what was measured)."""
         if not self.hip_outlier_guard or self.hip_precision_used not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC) or x.shape[0] == 0:
             return
         seen = eng.outlier_stats(x.shape[0], x.shape[1], reset=True)
@@ -449,16 +406,20 @@ class CondGaussianDiffusion(nn.Module):
         lim = [self.ENVELOPE_ABSOLUTE] * len(seen) if env is None else [self.ENVELOPE_MARGIN * max(v, 1e-30) for v in env]
         if all(s <= l for s, l in zip(seen, lim)):
             return
-        prec = self.hip_precision_used
+        prec, plan = self.hip_precision_used, self._slot.plan
         n = min(int(x.shape[0]), 8)
-        errors, _ = self._probe_precisions((prec,), probe=(x[:n].contiguous(), x_cond[:n].contiguous()))
-        if errors[prec] <= self.PROBE_LIMIT:
+        probe = PrecisionProbe(self, probe=(x[:n], x_cond[:n]), tail=self.PROBE_TAIL)
+        try:
+            err, _ = probe.error(plan["sd"] if plan["sd"] is not None else probe.sd, prec, plan["row_shift"])
+        finally:
+            probe.close()
+        if err <= self.PROBE_LIMIT:
             self._slot.envelope = [max(a, b) for a, b in zip(seen, env)] if env is not None else list(seen)
             return
         worst = max(range(len(seen)), key=lambda i: seen[i] / lim[i])
         msg = (f"LayerNorm rows of this chain peak at {seen[worst]:.1f} (layer {worst // 2}, "
                f"{'self_attn' if worst % 2 == 0 else 'pos_ffn'}.layer_norm), beyond what the pack-time probe validated, and precision "
-               f"{prec} differs from split-bf16 by {errors[prec]:.1e} on this chain's own tensors (limit {self.PROBE_LIMIT:.0e})")
+               f"{prec} differs from split-bf16 by {err:.1e} on this chain's own tensors (limit {self.PROBE_LIMIT:.0e})")
         if self.hip_precision == "auto":
             self._slot.demoted = self._slot.force_repack = True  # re-pack at the next call
             warnings.warn(msg + ": hip_precision='auto' uses split-bf16 (3) from the next call on", RuntimeWarning, stacklevel=4)
@@ -493,7 +454,7 @@ class CondGaussianDiffusion(nn.Module):
     def denoise(self, x, t, x_cond, padding_mask=None):
         """denoise_fn(cat(x, x_cond), t) on the HIP path."""
         self._check_t(t)
-        return self.hip_engine().denoise(self._f32c(x), self._f32c(x_cond), t.long().contiguous(), padding_mask)
+        return self.hip_engine(masked=padding_mask is not None).denoise(self._f32c(x), self._f32c(x_cond), t.long().contiguous(), padding_mask)
 
     def p_mean_variance(self, x, t, x_cond, clip_denoised, padding_mask=None):
         out = self.denoise(x, t, x_cond, padding_mask)
@@ -511,7 +472,7 @@ class CondGaussianDiffusion(nn.Module):
     def p_sample(self, x, t, x_cond, clip_denoised=True, padding_mask=None, noise=None):
         """One ancestral step (fused on the GPU).  `noise=None` draws torch.randn_like(x), exactly
         where the reference draws it."""
-        eng = self.hip_engine()
+        eng = self.hip_engine(masked=padding_mask is not None)
         self._check_t(t)
         if noise is None:
             noise = torch.randn_like(x)
@@ -528,7 +489,7 @@ class CondGaussianDiffusion(nn.Module):
         consumed in the reference's order (sampling_rng='torch') or the per-step noise is drawn in-kernel
         (sampling_rng='philox').
         """
-        eng = self.hip_engine(verify=True)
+        eng = self.hip_engine(verify=True, masked=padding_mask is not None)
         device = self.betas.device
         S = self.num_timesteps
         if noise is not None:

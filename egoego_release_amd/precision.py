@@ -1,0 +1,249 @@
+"""Pack-time measurement and preparation of a checkpoint for the int8-slice precisions (8, 9).
+
+The int8 precisions are 16-bit FIXED point with one scale per row (activations) / per output row (weights); split-bf16 (3) is 16-bit
+FLOATING point per element.  On the reference's initialisation both are far inside the 1e-3 bar; on weights that have been trained
+the fixed-point grid is about three bits coarser where it matters (measured on the trained-like checkpoint of
+tools/make_trained_like_checkpoint.py, round 4: precision 9 ends a chain 1.17e-3 from the fp32 oracle, precision 8 8.7e-4,
+precision 3 6e-5; tools/experiments/int8_site_study.py attributes 7.4e-4 of it to the WEIGHT grid alone — nearest rounding of the
+Q/K/V projections of a sharp, trained attention — and most of the rest to LayerNorm rows that carry one near-constant massive
+feature).  Two pack-time transformations, both invisible to the kernels and free at run time, buy most of it back:
+
+  * mean shift of the LayerNorm rows (`prepare_int8_state(shift=...)`): every LayerNorm output row is STORED minus a per-feature
+    constant m (the mean row over calibration tokens), so that its one scale no longer has to span a constant massive feature.
+    Every consumer of such a row is linear with a bias (the projections, FFN-1, linear_out) or a residual add next to a per-feature
+    bias, so the constant folds into biases and LayerNorm shifts:  beta' = beta - m,  b_consumer' = b_consumer + W m,
+    b_next_epilogue' = b + m.  The network function is unchanged in exact arithmetic (NOT under a padding mask, which zeroes rows
+    after the shift: masked calls get an engine without it).
+  * error-compensating rounding of the weights ON THE SAME INTEGER GRID (`compensated_rounding`, GPTQ: Frantar et al. 2022): the
+    rounding error of each weight column is pushed onto the not-yet-rounded columns along the inverse Hessian of the GEMM's
+    calibration inputs, minimising the OUTPUT error (W - W_q) x instead of the weight error.  The result is handed to the library as
+    fp32 values that sit exactly on its grid (k_pack_rows_i8 re-derives the same integers), so no kernel and no ABI changes.
+
+`PrecisionProbe` holds the split-bf16 reference engine and the probe batch: it measures a candidate (state dict, precision) against
+split-bf16 at the END OF A CHAIN (where a trained denoiser accumulates operand rounding) and on two forwards, and hands out the
+calibration rows (the reference engine's own stage taps: no PyTorch forward is involved).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import HipEngine, TR
+
+QMAX = 32639.0
+CAL_TIMESTEP_FRACTIONS = (0.0, 0.02, 0.1, 0.5, 1.0)  # calibration forwards at these fractions of the schedule
+
+
+def _engine_cfg(model):
+    d = model.denoise_fn
+    return dict(d_feats=d.d_feats, d_model=d.d_model, n_head=d.n_head, n_dec_layers=d.n_dec_layers, d_k=d.d_k, d_v=d.d_v,
+                max_timesteps=d.max_timesteps, num_timesteps=int(model.betas.shape[0]), objective=model.objective)
+
+
+class PrecisionProbe:
+    """Split-bf16 reference engine + probe batch of one module.  probe=(x, x_cond): measure on the caller's tensors (x taken as the
+    sample) instead of the seeded probe batch."""
+
+    B = 4
+    SEED = 20260401
+
+    def __init__(self, model, probe=None, tail=30):
+        self.model = model
+        self.dev = model.betas.device
+        self.cfg = _engine_cfg(model)
+        self.sd = model.state_dict()
+        self.S = int(model.betas.shape[0])
+        self.ref = HipEngine(self.cfg, self.sd, self.dev, _lib.PREC_BF16X3, _lib.FLAG_NO_GRAPH)
+        dev, S, D = self.dev, self.S, self.cfg["d_feats"]
+        g = torch.Generator().manual_seed(self.SEED)
+        self.cases = []
+        if probe is None:
+            B, T = self.B, model.seq_len
+            xT = torch.randn((B, T, D), generator=g).to(dev)
+            self.xc = torch.randn((B, T, D), generator=g).to(dev)
+            self.x0 = xT.clone()
+            ts = sorted({int(round(v)) for v in np.linspace(0, S - 1, min(10, S))}, reverse=True)
+            self.ref.ddim_loop_(self.x0, self.xc, ts)  # x0-like samples of this very model (deterministic DDIM, split-bf16)
+            self.cases.append((S - 1, xT))
+        else:
+            self.x0, self.xc = probe[0].contiguous(), probe[1].contiguous()
+            B, T = self.x0.shape[0], self.x0.shape[1]
+        self.Bp, self.T = B, T
+        self.eps = torch.randn((B, T, D), generator=g).to(dev)
+        if S > 2 and probe is None:
+            self.cases.append((S // 2, self._renoise(S // 2)))
+        self.n_tail = min(tail, S)
+        self.x_tail = self._renoise(self.n_tail - 1)
+        self._want = None
+
+    def _renoise(self, tv):
+        t = torch.full((self.Bp,), tv, device=self.dev, dtype=torch.long)
+        return self.model.q_sample(self.x0, t, self.eps).contiguous()
+
+    def _x0(self, raw, x, t):
+        m = self.model
+        x0 = raw if m.objective == "pred_x0" else m.predict_start_from_noise(x, t, raw)
+        return x0.clamp(-1.0, 1.0)
+
+    def _tail_chain(self, eng):
+        x = self.x_tail.clone()
+        eng.sample_loop_(x, self.xc, self.n_tail - 1, self.n_tail, noise_mode=_lib.NOISE_PHILOX, seed=self.SEED)
+        return x
+
+    def _reference(self):
+        if self._want is None:
+            fw = []
+            for tv, x in self.cases:
+                t = torch.full((self.Bp,), tv, device=self.dev, dtype=torch.long)
+                raw = self.ref.denoise(x, self.xc, t)
+                fw.append((self._x0(raw, x, t), raw, max(1.0, float(raw.abs().max()))))
+            self._want = (fw, self._tail_chain(self.ref))
+        return self._want
+
+    @torch.no_grad()
+    def error(self, sd, prec, row_shift=None):
+        """max over: the end of the probe's chain (final poses), and per forward the clamped x0 prediction (absolute) and the raw
+        output relative to max(1, |y|max) — of (sd, prec) against the split-bf16 engine on the module's own weights.
+        Returns (error, [row maxima per LayerNorm site the run recorded])."""
+        fw, tail = self._reference()
+        eng = HipEngine(self.cfg, sd, self.dev, prec, _lib.FLAG_NO_GRAPH, row_shift=row_shift)
+        try:
+            err = 0.0
+            for (tv, x), (w0, wraw, wmax) in zip(self.cases, fw):
+                t = torch.full((self.Bp,), tv, device=self.dev, dtype=torch.long)
+                raw = eng.denoise(x, self.xc, t)
+                err = max(err, float((self._x0(raw, x, t) - w0).abs().max()), float((raw - wraw).abs().max()) / wmax)
+            err = max(err, float((self._tail_chain(eng) - tail).abs().max()))
+            return err, eng.outlier_stats(self.Bp, self.T)
+        finally:
+            eng.close()
+
+    @torch.no_grad()
+    def calibration(self):
+        """Input rows of every GEMM and every LayerNorm-site mean, from the reference engine's stage taps on the probe samples
+        re-noised to a few timesteps.  {"rows": {(layer, 'qkv'|'fc'|'w_1'|'w_2') | ('out', 'linear_out'): [n, K]}, "n_layers": L}"""
+        L = self.cfg["n_dec_layers"]
+        rows = {}
+
+        def add(key, v):
+            rows.setdefault(key, []).append(v.reshape(-1, v.shape[-1]).float())
+        for tv in sorted({int(round(f * (self.S - 1))) for f in CAL_TIMESTEP_FRACTIONS}):
+            x = self._renoise(tv)
+            t = torch.full((self.Bp,), tv, device=self.dev, dtype=torch.long)
+            prev = self.ref.debug_stage(x, self.xc, t, 0, "embed")
+            for li in range(L):
+                add((li, "qkv"), prev)
+                add((li, "fc"), self.ref.debug_stage(x, self.xc, t, li, "attn_out"))
+                for st in ("k", "v"):  # [B, H, L, 256] -> rows of H * 256 features (the projections' output layout)
+                    v = self.ref.debug_stage(x, self.xc, t, li, st)
+                    add((li, st), v.permute(0, 2, 1, 3).reshape(v.shape[0], v.shape[2], -1))
+                add((li, "w_1"), self.ref.debug_stage(x, self.xc, t, li, "attn_ln"))
+                add((li, "w_2"), self.ref.debug_stage(x, self.xc, t, li, "ffn_hidden"))
+                prev = self.ref.debug_stage(x, self.xc, t, li, "out")
+            add(("out", "linear_out"), prev[:, 1:])
+        return {"rows": {k: torch.cat(v, 0) for k, v in rows.items()}, "n_layers": L}
+
+    def close(self):
+        self.ref.close()
+
+
+@torch.no_grad()
+def compensated_rounding(W, X, damp=0.01, block=128):
+    """W [out, in(, 1)] fp32, X [n, in] calibration input rows -> W_q on the library's int8-slice grid (q * rowmax / 32639, |q| <= 32639,
+    the row's largest entry kept in place so that the library derives the same scale), chosen column by column so that the rounding
+    error already made is compensated by the columns still to round (GPTQ).  fp32 on W's device; the Cholesky factors in float64 on
+    the CPU (rocSOLVER is not needed)."""
+    shape = W.shape
+    Wf = W.reshape(shape[0], -1).float().clone()
+    n_in = Wf.shape[1]
+    scale = (Wf.abs().amax(1, keepdim=True) / QMAX).clamp_min(1e-30)
+    Xd = X.double().cpu()
+    H = (Xd.T @ Xd) / max(1, Xd.shape[0])
+    H += damp * H.diagonal().mean().clamp_min(1e-12) * torch.eye(n_in, dtype=torch.float64)
+    U = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True).float().to(Wf.device)
+    Q = torch.empty_like(Wf)
+    for b0 in range(0, n_in, block):
+        b1 = min(b0 + block, n_in)
+        Wb = Wf[:, b0:b1].clone()
+        Eb = torch.empty_like(Wb)
+        for i in range(b1 - b0):
+            w = Wb[:, i]
+            q = torch.round(w / scale[:, 0]).clamp_(-QMAX, QMAX) * scale[:, 0]
+            Q[:, b0 + i] = q
+            e = (w - q) / U[b0 + i, b0 + i]
+            Eb[:, i] = e
+            if i + 1 < b1 - b0:
+                Wb[:, i + 1:] -= e[:, None] * U[b0 + i, b0 + i + 1:b1][None, :]
+        if b1 < n_in:
+            Wf[:, b1:] -= Eb @ U[b0:b1, b1:]
+    # the entry that sets the row's scale must stay the row maximum (the library takes the scale from max |w|)
+    orig = W.reshape(shape[0], -1).float()
+    imax = orig.abs().argmax(1, keepdim=True)
+    Q.scatter_(1, imax, torch.gather(orig, 1, imax))
+    return Q.reshape(shape)
+
+
+@torch.no_grad()
+def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=True):
+    """The state dict an int8-slice engine of precision `prec` is packed from: mean-shifted LayerNorm rows (folded into biases and
+    LayerNorm shifts), K / V minus their mean rows, and compensated rounding of the weights that precision contracts on int8
+    slices.  Returns (state dict, row_shift) where row_shift = {'embed' | (layer, 'attn_ln' | 'out' | 'k' | 'v' | 'attn_out'): m} are
+    the constants the stored tensors lack (the engine's debug taps add them back)."""
+    L = calib["n_layers"]
+    rows = calib["rows"]
+    out = dict(sd)
+    dev = next(iter(rows.values())).device
+
+    def get(k):  # (the latest version: several folds may touch one bias)
+        return out[k].detach().to(dev, torch.float32)
+    int8_w = {"qkv", "w_1", "w_2"} | ({"fc", "linear_out"} if prec == _lib.PREC_I8X3_FC else set())
+    names = {"qkv": ("self_attn.w_q", "self_attn.w_k", "self_attn.w_v"), "fc": ("self_attn.fc",), "w_1": ("pos_ffn.w_1",), "w_2": ("pos_ffn.w_2",)}
+    # ---- weights: compensated rounding on the grid the library will pack them onto
+    W = {}
+    for li in range(L):
+        for grp, nms in names.items():
+            for nm in nms:
+                k = f"{TR}layer_stack.{li}.{nm}.weight"
+                W[k] = compensated_rounding(get(k), rows[(li, grp)]) if (rounding and grp in int8_w) else get(k)
+    ko = "denoise_fn.linear_out.weight"
+    W[ko] = compensated_rounding(get(ko), rows[("out", "linear_out")]) if (rounding and "linear_out" in int8_w) else get(ko)
+    for k, v in W.items():
+        out[k] = v.to(sd[k].dtype).reshape(sd[k].shape)
+    row_shift = {}
+    # ---- K and V minus their mean row (valid under a padding mask as well, so both packings get it):
+    #   softmax_j(q_i . (k_j - c)) = softmax_j(q_i . k_j)   (the logits of a query all move by the same -q_i . c), and
+    #   sum_j p_ij (v_j - c) = O_i - c                       (a row of probabilities sums to 1), which fc's bias takes back: + W_fc c.
+    # Their int8 images (K: one scale per key row and head, V: one per feature column over the window's keys) then no longer spend
+    # their range on a constant.
+    kv_shift = {}
+    if shift_kv and (0, "k") in rows:
+        for li in range(L):
+            a = f"{TR}layer_stack.{li}.self_attn."
+            ck, cv = rows[(li, "k")].mean(0), rows[(li, "v")].mean(0)
+            out[a + "w_k.bias"] = get(a + "w_k.bias") - ck
+            out[a + "w_v.bias"] = get(a + "w_v.bias") - cv
+            out[a + "fc.bias"] = get(a + "fc.bias") + W[a + "fc.weight"].reshape(W[a + "fc.weight"].shape[0], -1) @ cv
+            kv_shift[(li, "k")], kv_shift[(li, "v")], kv_shift[(li, "attn_out")] = ck, cv, cv
+    if shift:
+        def w2(k):
+            return W[k].reshape(W[k].shape[0], -1)
+        m_in = [rows[(li, "qkv")].mean(0) for li in range(L)]          # layer inputs (embed output / previous LayerNorm-2)
+        m_a = [rows[(li, "w_1")].mean(0) for li in range(L)]           # LayerNorm-1 outputs
+        m_out = rows[("out", "linear_out")].mean(0)                    # last LayerNorm-2 output
+        out[TR + "start_conv.bias"] = get(TR + "start_conv.bias") - m_in[0]
+        out["denoise_fn.time_mlp.3.bias"] = get("denoise_fn.time_mlp.3.bias") - m_in[0]
+        row_shift["embed"] = m_in[0]
+        for li in range(L):
+            a, f = f"{TR}layer_stack.{li}.self_attn.", f"{TR}layer_stack.{li}.pos_ffn."
+            for nm in ("w_q", "w_k", "w_v"):
+                out[a + nm + ".bias"] = get(a + nm + ".bias") + w2(a + nm + ".weight") @ m_in[li]
+            out[a + "fc.bias"] = get(a + "fc.bias") + m_in[li]                       # the residual of LayerNorm-1 is the shifted row
+            out[a + "layer_norm.bias"] = get(a + "layer_norm.bias") - m_a[li]
+            out[f + "w_1.bias"] = get(f + "w_1.bias") + w2(f + "w_1.weight") @ m_a[li]
+            out[f + "w_2.bias"] = get(f + "w_2.bias") + m_a[li]                      # the residual of LayerNorm-2
+            m_next = m_in[li + 1] if li + 1 < L else m_out
+            out[f + "layer_norm.bias"] = get(f + "layer_norm.bias") - m_next
+            row_shift[(li, "attn_ln")] = m_a[li]
+            row_shift[(li, "out")] = m_next
+        out["denoise_fn.linear_out.bias"] = get("denoise_fn.linear_out.bias") + W[ko] @ m_out
+    row_shift.update(kv_shift)
+    return out, row_shift

@@ -81,8 +81,11 @@ def test_trained_like_forward_and_chain_against_oracle(trained):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for p in (_lib.PREC_BF16X3, _lib.PREC_I8X3, _lib.PREC_I8X3_FC):
-            models[p] = _build(sd, p)
-    must = ("auto", _lib.PREC_BF16X3, auto_prec)  # the bar is asserted for these; the others are reported
+            models[p] = _build(sd, p, hip_int8_prep="never")
+        # the pack-time preparation of precision.py (mean-shifted LayerNorm rows, compensated rounding) forced on
+        models["8 prepared"] = _build(sd, _lib.PREC_I8X3, hip_int8_prep="always")
+        models["9 prepared"] = _build(sd, _lib.PREC_I8X3_FC, hip_int8_prep="always")
+    must = ("auto", _lib.PREC_BF16X3)  # the bar is asserted for what auto runs and for the fallback; the other packings are reported
     # ---- one forward at three timesteps, x = q_sample of real-looking data
     for tv in (0, 500, 999):
         t = torch.full((B,), tv, dtype=torch.long)
@@ -112,6 +115,29 @@ def test_trained_like_forward_and_chain_against_oracle(trained):
     for p in must:
         assert errs[p] < POSE_TOL, (p, errs)
     assert models["auto"].hip_precision_used == auto_prec  # the runtime guard did not have to step in on a checkpoint the probe validated
+    # the prepared engines store mean-shifted rows; their debug taps add the constants back: the LayerNorm stops of the product
+    # kernels against the oracle's, and the rows really are shifted (the last layer's LayerNorm-1 rows carry a massive feature here)
+    mp = models["9 prepared"]
+    assert mp._slot.plan["prepared"] and mp._slot.plan["row_shift"]
+    tv = torch.full((B,), 20, dtype=torch.long)
+    xq = sched["sqrt_alphas_cumprod"][20] * data + sched["sqrt_one_minus_alphas_cumprod"][20] * eps
+    taps = {}
+    with torch.no_grad():
+        O.denoise(sd, torch.cat((xq, xc), -1), tv, taps=taps)
+    eng = mp.hip_engine()
+    for li, st in ((0, "attn_ln"), (3, "attn_ln"), (3, "out")):
+        got = eng.debug_stage(xq.cuda(), xc.cuda(), tv.cuda(), li, st).cpu()
+        want = taps[f"layer{li}"][st]
+        assert float((got - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max())), (li, st)
+    sh = mp._slot.plan["row_shift"][(3, "attn_ln")]
+    print("largest constant removed from the last layer's LayerNorm-1 rows:", float(sh.abs().max()), "of a row maximum of", float(taps["layer3"]["attn_ln"].abs().max()))
+    # a padding-mask call runs the unshifted packing of the same precision (a mask zeroes rows after the shift)
+    pm = torch.ones(B, 1, T + 1)
+    pm[:, :, -7:] = 0
+    with torch.no_grad():
+        want = O.denoise(sd, torch.cat((xq, xc), -1), tv, padding_mask=pm)
+    got = mp.denoise(xq.cuda(), tv.cuda(), xc.cuda(), padding_mask=pm.cuda()).cpu()
+    assert float((got - want).abs().max()) < POSE_TOL, float((got - want).abs().max())
 
 
 def test_runtime_outlier_guard_trips_on_massive_features_and_steps_down():
@@ -197,4 +223,4 @@ def test_guards_are_quiet_and_cheap_on_the_reference_initialisation():
     c0, g0 = torch.get_rng_state(), torch.cuda.get_rng_state()
     m2.hip_engine()
     assert torch.equal(c0, torch.get_rng_state()) and torch.equal(g0, torch.cuda.get_rng_state())
-    assert m2.hip_precision_probe["errors"][_lib.PREC_I8X3_FC] < m2.PROBE_LIMIT
+    assert m2.hip_precision_probe["errors"]["9 as is"] < m2.PROBE_LIMIT and not m2.hip_precision_probe["prepared"]

@@ -37,8 +37,9 @@ class Shim:
     """Stands in for torch.nn.functional inside the oracle.  `sites`: set of (layer, name) with name in
     ln1 / ln2 (LayerNorm outputs, rounded in place), o (attention output, per row and head), hid (ReLU rows), or ('all', name)."""
 
-    def __init__(self, sites):
+    def __init__(self, sites, shift=None):
         self.sites = sites
+        self.shift = shift
         self.layer = 0
         self.ln_count = 0
         self.crest = {}
@@ -57,7 +58,10 @@ class Shim:
         c = float((y.abs().amax(-1) / y.pow(2).mean(-1).sqrt()).max())
         self.crest[key] = max(self.crest.get(key, 0.0), c)
         if self.on(name):
-            y = quant15(y)
+            mu = self.shift.get(key) if self.shift else None
+            # (mean shift: the row is stored minus a per-feature constant; every consumer is linear (+ bias) or a residual add next to a
+            # per-feature bias, so the constant folds into biases / beta at pack time and costs nothing at run time)
+            y = quant15(y) if mu is None else quant15(y - mu) + mu
         self.ln_count += 1
         if name == "ln2":
             self.layer += 1
@@ -105,8 +109,8 @@ def main():
     x_cond = data * (1 - mask) + mask * nz["cond"]
     torch.set_num_threads(min(32, os.cpu_count() or 8))
 
-    def chain(weights, sites):
-        shim = Shim(sites)
+    def chain(weights, sites, shift=None):
+        shim = Shim(sites, shift)
         O.F = shim
         real_denoise = O.denoise
 
@@ -121,8 +125,8 @@ def main():
     ref, crest = chain(sd, set())
     print("worst row crest per LayerNorm site over the chain:", {f"L{k[0]}.{k[1]}": round(v, 1) for k, v in sorted(crest.items())})
 
-    def report(label, weights, sites):
-        out, _ = chain(weights, sites)
+    def report(label, weights, sites, shift=None):
+        out, _ = chain(weights, sites, shift)
         print(f"{label:70s} max|d| {float((out - ref).abs().max()):.2e}   mean|d| {float((out - ref).abs().mean()):.2e}", flush=True)
 
     # ---- which weights?  and: does correcting the biases for the weights' rounding help?
@@ -220,6 +224,16 @@ def main():
     report("GPTQ weights + bias correction", sdgc, set())
     report("GPTQ weights + bias correction + every activation site", sdgc, {("all", "ln1"), ("all", "ln2"), ("all", "o"), ("all", "hid")})
     report("GPTQ weights + every activation site", sdg, {("all", "ln1"), ("all", "ln2"), ("all", "o"), ("all", "hid")})
+    shift = {}
+    for li in range(4):
+        shift[(li, "ln1")] = mu[(li, "w_1")]
+        shift[(li, "ln2")] = mu[(li + 1, "qkv")] if li < 3 else torch.cat(rows[("out", "linear_out")], 0).mean(0)
+    allsites = {("all", "ln1"), ("all", "ln2"), ("all", "o"), ("all", "hid")}
+    report("nearest weights + every activation site, LayerNorm rows mean-shifted", sdq, allsites, shift)
+    report("GPTQ weights + every activation site, LayerNorm rows mean-shifted", sdg, allsites, shift)
+    report("GPTQ weights + bias correction + every activation site, LayerNorm rows mean-shifted", sdgc, allsites, shift)
+    _, cr = chain(sd, set())
+    print("LayerNorm row crest after the mean shift:", {f"L{k[0]}.{k[1]}": round(float(((torch.cat(rows[(k[0], 'w_1')] if k[1] == 'ln1' else (rows[(k[0] + 1, 'qkv')] if k[0] < 3 else rows[('out', 'linear_out')]), 0) - v).abs().amax(-1) / (torch.cat(rows[(k[0], 'w_1')] if k[1] == 'ln1' else (rows[(k[0] + 1, 'qkv')] if k[0] < 3 else rows[('out', 'linear_out')]), 0) - v).pow(2).mean(-1).sqrt()).max()), 1) for k, v in shift.items()})
     report("weights + bias correction + every activation site", sdc, {("all", "ln1"), ("all", "ln2"), ("all", "o"), ("all", "hid")})
     report("weights only (int8 slices, one scale per output row)", sdq, set())
     report("weights + every activation site (the precision-9 emulation)", sdq, {("all", "ln1"), ("all", "ln2"), ("all", "o"), ("all", "hid")})

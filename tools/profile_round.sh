@@ -4,7 +4,7 @@
 #   1. the bench lines                                   python bench.py [--batch ..] [--window ..]
 #   2. per-kernel time summaries                         rocprofv3 --kernel-trace --stats  (same commands, fewer steps)
 #   3. PMC counters, three separate passes               rocprofv3 --kernel-trace --pmc ...   (no --sys-trace etc.)
-R=${EGOEGO_ROUND:-r03}
+R=${EGOEGO_ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
