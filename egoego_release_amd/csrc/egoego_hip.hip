@@ -15,6 +15,7 @@
 #include "attn_layer_i8.h"
 #include "attn_layer_i8w.h"
 #include "attn_layer_i8h.h"
+#include "attn_layer_i8x.h"
 #include "attn_split_i8.h"
 #include "attn_core_i8.h"
 #include "common.h"
@@ -478,8 +479,16 @@ static int launch_tail_f(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_
 #endif
 // ... and as TWO eight-wave workgroups per (window, head), 1.5 projections each, + the core launch for 22..32 windows (one round of
 // the chip where the three-workgroup form takes 1.5 and the one-kernel forms leave half of it idle)
+// (measured, round 4, ms per step at B = 22 / 24 / 28 / 32: 0.272 / 0.281 / 0.305 / 0.321 with it, 0.279 / 0.286 / 0.302 / 0.307 without:
+// with every CU busy the images' L2 round trip and the fuller chip's clock cost more than the shorter chain saves — it replaces the
+// half-query form for 22..24 windows and stops there)
 #ifndef ATTN_SPLIT2_MAX_BLOCKS
-#define ATTN_SPLIT2_MAX_BLOCKS 256
+#define ATTN_SPLIT2_MAX_BLOCKS 192
+#endif
+// the one-kernel attention layer with the projections' weights global -> VGPR and 8 (f) x 1 (t) waves (attn_layer_i8x.h) instead of
+// the LDS-ring form (attn_layer_i8w.h)
+#ifndef ATTN_LAYER_X
+#define ATTN_LAYER_X 1
 #endif
 #ifndef ATTN_HALF_MAX_BLOCKS
 #define ATTN_HALF_MAX_BLOCKS 192
@@ -684,6 +693,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             static DevOnce once;
             if (once.pending()) {
                 HIP_TRY(allow_smem(attn_layer_i8w_kernel, AL_SMEM_BYTES));
+                HIP_TRY(allow_smem(attn_layer_i8x_kernel, ALX_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_proj_i8_kernel, ATTN_PROJ_SMEM));
                 HIP_TRY(allow_smem(attn_core_s_kernel, ATTN_CORE_S_SMEM));
@@ -716,6 +726,9 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             if (nw * H * 2 <= ATTN_HALF_MAX_BLOCKS) {
                 c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8h_kernel";
                 attn_layer_i8h_kernel<<<dim3(nw * H * 2), dim3(512), AL_SMEM_BYTES, s>>>(al);
+            } else if (ATTN_LAYER_X) {
+                c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8x_kernel";
+                attn_layer_i8x_kernel<<<dim3(nw * H), dim3(512), ALX_SMEM_BYTES, s>>>(al);
             } else {
                 c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8w_kernel";
                 attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AL_SMEM_BYTES, s>>>(al);

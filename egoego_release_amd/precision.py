@@ -183,7 +183,7 @@ def compensated_rounding(W, X, damp=0.01, block=128):
 
 
 @torch.no_grad()
-def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=True):
+def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=False):
     """The state dict an int8-slice engine of precision `prec` is packed from: mean-shifted LayerNorm rows (folded into biases and
     LayerNorm shifts), K / V minus their mean rows, and compensated rounding of the weights that precision contracts on int8
     slices.  Returns (state dict, row_shift) where row_shift = {'embed' | (layer, 'attn_ln' | 'out' | 'k' | 'v' | 'attn_out'): m} are
@@ -213,7 +213,8 @@ def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=True
     #   softmax_j(q_i . (k_j - c)) = softmax_j(q_i . k_j)   (the logits of a query all move by the same -q_i . c), and
     #   sum_j p_ij (v_j - c) = O_i - c                       (a row of probabilities sums to 1), which fc's bias takes back: + W_fc c.
     # Their int8 images (K: one scale per key row and head, V: one per feature column over the window's keys) then no longer spend
-    # their range on a constant.
+    # their range on a constant.  OFF by default: measured on the trained-like checkpoint (round 4) it moved nothing — forwards
+    # 1.4-1.7e-4 with and without, the end of the chain 7.4e-4 without and 8.7e-4 with (inside the noise of a 5x-amplifying chain).
     kv_shift = {}
     if shift_kv and (0, "k") in rows:
         for li in range(L):

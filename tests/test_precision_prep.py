@@ -32,8 +32,8 @@ def test_mean_shift_is_function_preserving_and_rows_are_shifted():
     cfg = ModelConfig(max_timesteps=25)
     sd = make_weights(cfg, 0)
     calib = _calibration(sd)
-    sd2, shift = prepare_int8_state(sd, calib, _lib.PREC_I8X3_FC, shift=True, rounding=False)
-    assert set(shift) == {"embed"} | {(li, s) for li in range(4) for s in ("attn_ln", "out", "k", "v", "attn_out")}
+    sd2, shift = prepare_int8_state(sd, calib, _lib.PREC_I8X3_FC, shift=True, rounding=False, shift_kv=True)
+    assert set(shift) == {"embed"} | {(li, s) for li in range(4) for s in ("attn_ln", "out", "k", "v", "attn_out")}  # (shift_kv=True below)
     assert float(shift[(0, "attn_ln")].abs().max()) > 0.05  # the rows do have a common component to remove
     x_all = torch.randn(2, 24, 396, generator=torch.Generator().manual_seed(9))
     t = torch.tensor([5, 700])
