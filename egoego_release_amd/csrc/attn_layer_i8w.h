@@ -49,12 +49,9 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
         (void)i;
     };
     mark(0);
-#ifdef ATTN_PRIO
-    // experiment (MI355X_MICROARCH.md "static priority for the younger half"): the second-dispatched waves of an 8-wave workgroup lose
-    // every VALU / MFMA arbitration against their SIMD partners; one s_setprio for that half, no per-phase flips
-    if (wave >= 4) __builtin_amdgcn_s_setprio(ATTN_PRIO);
-#endif
-    {
+    // the per-feature parameters of the head and the window's row scales -> LDS; issued from inside the K projection's prologue, behind its
+    // pipeline-fill LDS-DMA (in front of it, their round trip preceded the fill's: round 4); visible after that main loop's first barrier
+    auto stage_params = [&] {
         const int HD = a.H * 256;
         for (int i = threadIdx.x; i < 768; i += 512) {
             const int src = (i >> 8) * HD + h * 256 + (i & 255);
@@ -62,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
             p_b[i] = a.bias[src];
         }
         if (threadIdx.x < 128) p_hs[threadIdx.x] = a.h_scale[b * 128 + threadIdx.x];
-    }  // visible after the first barrier of the K projection's main loop
+    };
 
     // One row-quantising projection epilogue for K and Q: dequantise, bias (x qs), maximum over the head's 256 features of each
     // token (in-lane over the wave's 64, then across the 4 feature waves through LDS), two int8 slices into `img`.
@@ -114,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
     // ---- 1. K_h -> LDS ------------------------------------------------------------------------------
     {
         I8Acc q[2][2];
-        GemmBody<AW8K, NoEpi>::mainloop(g, a.H + h, b, ring, q);
+        GemmBody<AW8K, NoEpi>::mainloop(g, a.H + h, b, ring, q, stage_params);
         mark(1);
         // (the 4-wave form adds the bias without a scale: x 1.0f is exact)
         rows_epilogue(q, 1, 1.0f, sk, kv);

@@ -15,7 +15,6 @@
 #include "attn_layer_i8.h"
 #include "attn_layer_i8w.h"
 #include "attn_layer_i8h.h"
-#include "attn_layer_i8x.h"
 #include "attn_split_i8.h"
 #include "attn_core_i8.h"
 #include "common.h"
@@ -485,11 +484,8 @@ static int launch_tail_f(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_
 #ifndef ATTN_SPLIT2_MAX_BLOCKS
 #define ATTN_SPLIT2_MAX_BLOCKS 192
 #endif
-// the one-kernel attention layer with the projections' weights global -> VGPR and 8 (f) x 1 (t) waves (attn_layer_i8x.h) instead of
-// the LDS-ring form (attn_layer_i8w.h)
-#ifndef ATTN_LAYER_X
-#define ATTN_LAYER_X 1
-#endif
+// (round 4 also built the one-kernel layer with the projections' weights global -> VGPR and 8 (f) x 1 (t) waves — bit-identical, and
+// SLOWER: 1.445 against 1.368 ms per step at B=256, 0.331 against 0.304 at B=32; git history "attn_layer_i8x.h", HISTORY.md R4)
 #ifndef ATTN_HALF_MAX_BLOCKS
 #define ATTN_HALF_MAX_BLOCKS 192
 #endif
@@ -693,7 +689,6 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             static DevOnce once;
             if (once.pending()) {
                 HIP_TRY(allow_smem(attn_layer_i8w_kernel, AL_SMEM_BYTES));
-                HIP_TRY(allow_smem(attn_layer_i8x_kernel, ALX_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_proj_i8_kernel, ATTN_PROJ_SMEM));
                 HIP_TRY(allow_smem(attn_core_s_kernel, ATTN_CORE_S_SMEM));
@@ -726,9 +721,6 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             if (nw * H * 2 <= ATTN_HALF_MAX_BLOCKS) {
                 c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8h_kernel";
                 attn_layer_i8h_kernel<<<dim3(nw * H * 2), dim3(512), AL_SMEM_BYTES, s>>>(al);
-            } else if (ATTN_LAYER_X) {
-                c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8x_kernel";
-                attn_layer_i8x_kernel<<<dim3(nw * H), dim3(512), ALX_SMEM_BYTES, s>>>(al);
             } else {
                 c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8w_kernel";
                 attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AL_SMEM_BYTES, s>>>(al);

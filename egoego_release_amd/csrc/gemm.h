@@ -147,8 +147,13 @@ struct GemmBody {
     // main loop only: on return acc[ft][tt] holds the pre-epilogue sums of this wave's tile.
     // AccT = f32x16 (bf16 operands) or I8Acc (int8 slices: g.K16 then counts 32-wide k blocks).
     // ZERO = false: accumulate on top of what acc holds (second pass of the I8One form)
-    template <class AccT, bool ZERO = true>
-    static __device__ void mainloop(const GemmOperands& g, int fblk, int tblk, char* smem, AccT (&acc)[C::FT][C::TT]) {
+    struct NoPre {
+        EG_D void operator()() const {}
+    };
+    // pre(): called once, after the pipeline-fill LDS-DMA of the prologue has been requested and before it is waited for — work with a
+    // memory round trip of its own (a kernel's parameter staging) then shares the fill's instead of preceding it
+    template <class AccT, bool ZERO = true, class Pre = NoPre>
+    static __device__ void mainloop(const GemmOperands& g, int fblk, int tblk, char* smem, AccT (&acc)[C::FT][C::TT], Pre pre = Pre{}) {
         constexpr int FT = C::FT, TT = C::TT, KS = C::KS, NP = C::NP, WT = C::WT, AT = C::AT, NW = C::NW;
         constexpr int NCH = C::NCH;
         const int wave = wave_id_uniform();
@@ -286,6 +291,7 @@ struct GemmBody {
         const int nu = ns * KS;
         int slot = 0;   // slot of the stage being read
         int pslot = 0;  // slot of the previous stage (the one being refilled)
+        pre();
         wait_stage(0);
         if (D < ns && loads_on) {  // stage D goes into the one slot the prologue left empty
 #pragma unroll

@@ -244,9 +244,14 @@ struct DirectGemm {
         EG_D void operator()(int) const {}
     };
     // post(q): called after the MFMAs of chunk q (8 k-blocks), e.g. to fold a chunk's integer sums away (int8 fc)
-    template <class Mark, class Post = NoPost>
+    struct NoPre {
+        EG_D void operator()() const {}
+    };
+    // pre(): called once in the prologue, AFTER the first chunk's pieces and the first weight fragments have been requested and
+    // before they are waited for — work that needs a memory round trip of its own (the tail's parameter staging) then shares theirs
+    template <class Mark, class Post = NoPost, class Pre = NoPre>
     static EG_D void run(AccT (&acc)[FT][TT], const __bf16* in, size_t in_plane, int K16, const __bf16* w, size_t w_plane, char* act,
-                         int tt0, int wave, int lane, Mark mark, int wtile0 = -1, Post post = Post{}) {
+                         int tt0, int wave, int lane, Mark mark, int wtile0 = -1, Post post = Post{}, Pre pre = Pre{}) {
         const int wt0 = wtile0 >= 0 ? wtile0 : wave * FT;  // first weight row tile of this wave (default: FT consecutive tiles per wave)
         i32x4 wq[RING][NW];
         // The activation resource starts at THIS workgroup's first row tile (64-bit address arithmetic on the scalar unit), so the
@@ -284,6 +289,7 @@ struct DirectGemm {
         for (int i = 0; i < FT; ++i)
 #pragma unroll
             for (int j = 0; j < TT; ++j) acc_zero(acc[i][j]);
+        pre();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         mark();
@@ -398,14 +404,20 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
     // All-int8 build: the ten per-feature parameter vectors of the three epilogues (weight row scales, biases, LayerNorm gains
     // and shifts) are staged in LDS once per workgroup — the epilogues of a 32-token workgroup are load-latency chains, and an
     // LDS read costs a tenth of an L2 round trip.  Visible after the first GEMM's prologue barrier.
+    // (Round 4: the copy is issued from INSIDE the first GEMM's prologue, behind its first chunk's pieces and first weight fragments —
+    // placed in front of them, as it was, its loads were waited for before those were even requested: two dependent memory round
+    // trips at the start of every workgroup, 16-21 us of a workgroup's 66 at B=256 in the phase trace.)
     const float *p_swfc = a.s_wfc, *p_sw1 = a.s_w1, *p_sw2 = a.s_w2;
-    if constexpr (FFN8 && FC8) {
+    const float* const par_src[10] = {a.s_wfc, a.ln1.bias, a.ln1.gamma, a.ln1.beta, a.s_w1, a.relu8.bias, a.s_w2, a.ln2.bias, a.ln2.gamma, a.ln2.beta};
+    auto stage_params = [&] {
         float* par = (float*)(smem + tail_smem_bytes(TT, NWV));
-        const float* src[10] = {a.s_wfc, a.ln1.bias, a.ln1.gamma, a.ln1.beta, a.s_w1, a.relu8.bias, a.s_w2, a.ln2.bias, a.ln2.gamma, a.ln2.beta};
         if (threadIdx.x < 128) {
 #pragma unroll
-            for (int v = 0; v < 10; ++v) *(float4*)(par + v * 512 + 4 * threadIdx.x) = *(const float4*)(src[v] + 4 * threadIdx.x);
+            for (int v = 0; v < 10; ++v) *(float4*)(par + v * 512 + 4 * threadIdx.x) = *(const float4*)(par_src[v] + 4 * threadIdx.x);
         }
+    };
+    if constexpr (FFN8 && FC8) {
+        float* par = (float*)(smem + tail_smem_bytes(TT, NWV));
         p_swfc = par;
         a.ln1.bias = par + 512; a.ln1.gamma = par + 1024; a.ln1.beta = par + 1536;
         p_sw1 = par + 2048; a.relu8.bias = par + 2560;
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
                                 i8_fold(q[i][j], acc[fp * FTP + i][j], so[j]);
                                 acc_zero(q[i][j]);
                             }
-                    });
+                    }, [&] { if (fp == 0) stage_params(); });
         }
 #pragma unroll
         for (int i = 0; i < FT; ++i)

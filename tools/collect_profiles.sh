@@ -4,7 +4,7 @@
 R=${EGOEGO_ROUND:-r04}
 O=gpurun_out/$R
 set -e
-for f in bench_b256_t120 bench_b32_t120 bench_b64_t120 bench_b128_t120 bench_b256_t196 bench_2ranks_gloo_one_gpu bench_1rank_rccl_forced_gather; do
+for f in bench_b256_t120 bench_b32_t120 bench_b64_t120 bench_b128_t120 bench_b256_t196 bench_2ranks_gloo_one_gpu bench_1rank_rccl_forced_gather bench_b256_t120_trained_like bench_b256_t120_trained_like_p3; do
   grep -h "^{" $O/$f.json | tail -1 > profiles/${R}_$f.json
 done
 cp $O/step_times.jsonl profiles/${R}_step_times.jsonl
@@ -13,5 +13,6 @@ cp $(find $O/stats_b32 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_
 cp $(find $O/stats_t196 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_b256_t196_kernel_stats.csv
 A=$(find $O/pmc_a -name "*counter_collection.csv" | head -1); B=$(find $O/pmc_b -name "*counter_collection.csv" | head -1); C=$(find $O/pmc_c -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $A $B $C > profiles/${R}_pmc_per_kernel.csv
+python3 tools/fetch_calib.py $(find $O/calib_f -name "*counter_collection.csv" | head -1) $(find $O/calib_w -name "*counter_collection.csv" | head -1) > profiles/${R}_fetch_calibration.json
 EGOEGO_ROUND=$R python3 tools/traffic_json.py $A $B 256 120 9
 EGOEGO_ROUND=$R python3 tools/roofline_report.py
