@@ -128,6 +128,9 @@ def main():
                     help="synthetic: the seeded initialisation-distribution weights; trained-like: the same after --train-steps Adam steps of the "
                          "module's own training loss on synthetic motion (tools/make_trained_like_checkpoint.py; trained on this GPU before the bench)")
     ap.add_argument("--train-steps", type=int, default=3000)
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the pack-time precision probe (profiling runs: its small-batch launches would mix into per-kernel averages); "
+                         "needs an explicit --precision")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step (no hipGraph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="rank 0 saves the gathered poses of the timed call here (tests)")
@@ -183,6 +186,11 @@ def main():
     model = CondGaussianDiffusion(**cfg.ctor_kwargs())
     model.load_state_dict(sd, strict=False)
     model.hip_precision = "auto" if args.precision == "auto" else int(args.precision)
+    if args.no_probe:
+        if args.precision == "auto":
+            raise SystemExit("--no-probe needs an explicit --precision")
+        model.hip_probe_at_pack = False
+        model.hip_outlier_guard = False
     model.hip_graph = not args.no_graph
     model = model.to(dev)
     eng = model.hip_engine(verify=True)
@@ -318,7 +326,7 @@ def main():
         tail_roof = {
             "bound": "mfma", "kernel": f"{tail_full} ({TAIL_TXT.get(tail_name, '')})",
             "achieved": tail_ach, "peak": tail_peak, "unit": tail_unit, "frac": (tail_ach / tail_peak) if tail_ach else None,
-            "traffic": (traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
+            "traffic": (traffic.get(tail_full) or traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
             # precision 9: the attention output (1024 x 2 B), the residual rows in and the layer's rows out (512 x 2 B each) per token
             # + the int8 weights once; the other precisions: split-bf16 rows (4 B per value) incl. the hidden activations
             "algorithmic_bytes": (2 * Bl * L * (1024 + 512 + 512) + 2.1e6) if fc8 else (4 * Bl * L * (1024 + 512 + 512) + 4.2e6),

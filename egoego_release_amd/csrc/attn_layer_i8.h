@@ -50,6 +50,46 @@ struct NoEpi {};
 
 EG_D i32x4 lds_frag(const char* p) { return *(const i32x4*)p; }
 
+// ---- the probabilities as THREE int8 slices (round 4) -----------------------------------------------------------------------
+// p = exp2(s - rowmax) lies in (0, 1] with the row's largest entry exactly 1, so one fixed scale serves every row — but two slices
+// (steps of 1 / 32639) leave every small probability an ABSOLUTE error of 1.5e-5, and a trained, peaked attention sums ~120 of them
+// against a small row sum: tools/experiments/int8_site_study.py puts the P image at 4.5e-4 of a trained-like chain's error where
+// everything else together (prepared packing) makes 2.6e-4, and Q, K, V images add nothing.  So P gets a third slice:
+//     q = rint(p * 8355711) = 65536 a1 + 256 a2 + a3   (a1 in 0..127, a2, a3 signed bytes; 8355711 = 127 * 65536 + 127 * 256 + 127:
+//     the top slice keeps the 7 bits the two-slice form had, so the dropped a2 v2 term is no larger than its b2 v2 was — with a1
+//     only 6 bits wide, the first version, the DIFFUSE attention of the initialisation got WORSE: 4.0e-4 against 2.9e-4 at the
+//     attention output),
+// and PV a third int32 accumulator for the new level:  H += v1 a1,  M += v2 a1 + v1 a2,  L += v1 a3   (v = 256 v1 + v2; the terms
+// a2 v2 and a3 v2 are dropped like s2 s2 everywhere else) — four MFMAs per (d_v tile, key block) instead of three, in the PV phase
+// only (1/16 of the kernel's MFMAs).  Exact integers; the sum 2^8 (2^8 (2^8 H + M) + L) is formed as
+// fma(float(256 H + M), 256, float(L)), one function for every kernel form (same bits in all of them).
+static constexpr float P_QMAX = 8355711.0f;
+struct PVAcc {
+    i32x16 h, m, l;
+};
+EG_D void acc_zero(PVAcc& c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c.h[r] = c.m[r] = c.l[r] = 0;
+}
+// 16 probabilities in [0, 1] -> three slices of 16 bytes.  q = rint(p * P_QMAX) < 2^23 (v_rndne + v_cvt: the float-adder trick of
+// common.h quant16 stops at 2^22); byte 0 of q is a3, byte 1 of q + 128 is a2, byte 2 of q + 128 + 32768 is a1.
+EG_D void quant_p(const float v[16], u32x4& s1, u32x4& s2, u32x4& s3) {
+    uint32_t q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = (uint32_t)(int)__builtin_rintf(v[i] * P_QMAX);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t a = q[4 * w], b = q[4 * w + 1], c = q[4 * w + 2], d = q[4 * w + 3];
+        s3[w] = __builtin_amdgcn_perm(b, a, 0x0c0c0400u) | __builtin_amdgcn_perm(d, c, 0x04000c0cu);
+        const uint32_t a1 = a + 128u, b1 = b + 128u, c1 = c + 128u, d1 = d + 128u;
+        s2[w] = __builtin_amdgcn_perm(b1, a1, 0x0c0c0501u) | __builtin_amdgcn_perm(d1, c1, 0x05010c0cu);
+        const uint32_t a2 = a1 + 32768u, b2 = b1 + 32768u, c2 = c1 + 32768u, d2 = d1 + 32768u;
+        s1[w] = __builtin_amdgcn_perm(b2, a2, 0x0c0c0602u) | __builtin_amdgcn_perm(d2, c2, 0x06020c0cu);
+    }
+}
+// the value of one accumulator element in units of s_v / P_QMAX / 256 ... i.e. O = pv_value(..) * (s_v * (1 / rowsum) * 256 / P_QMAX)
+EG_D float pv_value(int h, int m, int l) { return __builtin_fmaf((float)i8_combine(h, m), 256.0f, (float)l); }
+
 // (The kernel itself is attn_layer_i8w.h: eight waves, two per SIMD.  Round 1-2's four-wave form — one 512-register wave per SIMD, Q
 // projected with a lane owning all 256 d_k of its query — ran 206-210 us per launch at B=256 where the eight-wave form runs 191.)
 

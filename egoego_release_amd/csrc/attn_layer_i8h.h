@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8h_kernel(AttnLayerArgs a)
         __syncthreads();  // the Q image is in registers: the ring may be refilled (V projection)
     }
     // ---- 3. S^T = K Q^T, softmax over keys (TM:76-82): wave (query tile qt, key tile kt) ---------------------------------
-    i32x4 ps1, ps2;  // this wave's key block of the probabilities
+    i32x4 ps1, ps2, ps3;  // this wave's key block of the probabilities, three slices (attn_layer_i8.h quant_p)
     {
         I8Acc s;
         acc_zero(s);
@@ -194,10 +194,11 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8h_kernel(AttnLayerArgs a)
         }
         s1 += __shfl_xor(s1, 32);
         if (hf == 0) psum[kt * 64 + qt * 32 + col] = s1;  // read in phase 5, behind the V projection's barriers
-        u32x4 u1, u2;
-        quant16(p, I8_QMAX, u1, u2);
+        u32x4 u1, u2, u3;
+        quant_p(p, u1, u2, u3);
         ps1 = __builtin_bit_cast(i32x4, u1);
         ps2 = __builtin_bit_cast(i32x4, u2);
+        ps3 = __builtin_bit_cast(i32x4, u3);
     }
     // ---- 4. V_h -> LDS (transposed, over the K image; all 128 keys; attn_layer_i8w.h phase 4) -------------------------------
     {
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8h_kernel(AttnLayerArgs a)
             char* dst = ring + ((qt * 4 + kt) << 10) + lane * 16;
             *(i32x4*)dst = ps1;
             *(i32x4*)(dst + 8192) = ps2;
+            *(i32x4*)(dst + 16384) = ps3;
         }
         const int f0 = 512 + wf * 64, t0 = wt * 64;
         f32x16 v[2][2];
@@ -252,16 +254,17 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8h_kernel(AttnLayerArgs a)
     // ---- 5. O^T = V^T P (TM:83-88): wave (query tile qt, d_v quarter dvq), heads merged on store ---------------------------
     const int dvq = kt;
     const int m = b * 128 + qh * 64 + qt * 32 + col;
-    i32x4 pa1[4], pa2[4];  // all four key blocks of this wave's query tile
+    i32x4 pa1[4], pa2[4], pa3[4];  // all four key blocks of this wave's query tile, three slices
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         const char* src = ring + ((qt * 4 + kb) << 10) + lane * 16;
         pa1[kb] = lds_frag(src);
         pa2[kb] = lds_frag(src + 8192);
+        pa3[kb] = lds_frag(src + 16384);
     }
     const int qi = qt * 32 + col;
-    const float oscale = (1.0f / ((psum[qi] + psum[64 + qi]) + (psum[128 + qi] + psum[192 + qi]))) * (256.0f / I8_QMAX);
-    I8Acc o[2];
+    const float oscale = (1.0f / ((psum[qi] + psum[64 + qi]) + (psum[128 + qi] + psum[192 + qi]))) * (256.0f / P_QMAX);
+    PVAcc o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) acc_zero(o[dt]);
 #pragma unroll
@@ -276,9 +279,11 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8h_kernel(AttnLayerArgs a)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], pa1[kb], o[dt].m, 0, 0, 0);
 #pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa1[kb], o[dt].h, 0, 0, 0);
+#pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa2[kb], o[dt].m, 0, 0, 0);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa1[kb], o[dt].h, 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt) o[dt].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa3[kb], o[dt].l, 0, 0, 0);
     }
     float t[2][16];
     float amax = 0.f;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8h_kernel(AttnLayerArgs a)
             const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float val = (float)i8_combine(o[dt].h[4 * gq + c], o[dt].m[4 * gq + c]) * (ss[c] * oscale);
+                const float val = pv_value(o[dt].h[4 * gq + c], o[dt].m[4 * gq + c], o[dt].l[4 * gq + c]) * (ss[c] * oscale);
                 t[dt][4 * gq + c] = val;
                 amax = fmaxf(amax, fabsf(val));
             }

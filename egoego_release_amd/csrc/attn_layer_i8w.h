@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
     }
     mark(4);
     // ---- 3. S^T = K Q^T, softmax over keys (TM:76-82): wave (query tile wave & 3, key half wave >> 2) -----------------------
-    i32x4 ps1[2], ps2[2];  // this wave's two key blocks of the probabilities
+    i32x4 ps1[2], ps2[2], ps3[2];  // this wave's two key blocks of the probabilities, three slices
     {
         const int qt3 = wave & 3, kh = wave >> 2;
         I8Acc s[2];
@@ -198,10 +198,11 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
         if (hf == 0) psum[kh * 128 + qt3 * 32 + col] = sum;  // read in phase 5, behind the V projection's barriers
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            u32x4 s1, s2;
-            quant16(p[kt], I8_QMAX, s1, s2);
+            u32x4 s1, s2, s3;
+            quant_p(p[kt], s1, s2, s3);
             ps1[kt] = __builtin_bit_cast(i32x4, s1);
             ps2[kt] = __builtin_bit_cast(i32x4, s2);
+            ps3[kt] = __builtin_bit_cast(i32x4, s3);
         }
     }
     mark(5);  // (thread 0 belongs to wave 0: after its S^T + softmax)
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
             char* dst = ring + (((wave & 3) * 4 + 2 * (wave >> 2) + kt) << 10) + lane * 16;
             *(i32x4*)dst = ps1[kt];
             *(i32x4*)(dst + 16384) = ps2[kt];
+            *(i32x4*)(dst + 32768) = ps3[kt];
         }
         const int f0 = 512 + wf * 64, t0 = wt * 64;
         f32x16 v[2][2];
@@ -261,48 +263,56 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
     // ---- 5. O^T = V^T P (TM:83-88): wave (query tile qt, d_v half dvh), heads merged on store -----------------------
     const int qt = wave & 3, dvh = wave >> 2;
     const int m = b * 128 + qt * 32 + col;
-    i32x4 pa1[4], pa2[4];  // all four key blocks of this wave's query tile
+    i32x4 pa1[4], pa2[4], pa3[4];  // all four key blocks of this wave's query tile, three slices (attn_layer_i8.h quant_p)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         const char* src = ring + ((qt * 4 + kb) << 10) + lane * 16;
         pa1[kb] = lds_frag(src);
         pa2[kb] = lds_frag(src + 16384);
+        pa3[kb] = lds_frag(src + 32768);
     }
-    const float oscale = (1.0f / (psum[qt * 32 + col] + psum[128 + qt * 32 + col])) * (256.0f / I8_QMAX);
-    I8Acc o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc_zero(o[dt]);
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        i32x4 v1[4], v2[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const char* src = kv + (((dvh * 4 + dt) * 4 + kb) << 10) + lane * 16;
-            v1[dt] = lds_frag(src);
-            v2[dt] = lds_frag(src + AL_SLICE);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], pa1[kb], o[dt].m, 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa2[kb], o[dt].m, 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa1[kb], o[dt].h, 0, 0, 0);
-    }
+    const float oscale = (1.0f / (psum[qt * 32 + col] + psum[128 + qt * 32 + col])) * (256.0f / P_QMAX);
     float t[4][16];
     float amax = 0.f;
+    // two d_v tiles at a time (three int32 accumulators per tile: the four at once would not leave room for their float results)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dp = 0; dp < 2; ++dp) {
+        PVAcc o[2];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 s4 = *(const float4*)(sv + (dvh * 4 + dt) * 32 + 8 * gq + 4 * hf);
-            const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+        for (int dt = 0; dt < 2; ++dt) acc_zero(o[dt]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float val = (float)i8_combine(o[dt].h[4 * gq + c], o[dt].m[4 * gq + c]) * (ss[c] * oscale);
-                t[dt][4 * gq + c] = val;
-                amax = fmaxf(amax, fabsf(val));
+        for (int kb = 0; kb < 4; ++kb) {
+            i32x4 v1[2], v2[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* src = kv + (((dvh * 4 + 2 * dp + dt) * 4 + kb) << 10) + lane * 16;
+                v1[dt] = lds_frag(src);
+                v2[dt] = lds_frag(src + AL_SLICE);
             }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], pa1[kb], o[dt].m, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa1[kb], o[dt].h, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa2[kb], o[dt].m, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa3[kb], o[dt].l, 0, 0, 0);
         }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 s4 = *(const float4*)(sv + (dvh * 4 + 2 * dp + dt) * 32 + 8 * gq + 4 * hf);
+                const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = 4 * gq + c;
+                    const float val = pv_value(o[dt].h[r], o[dt].m[r], o[dt].l[r]) * (ss[c] * oscale);
+                    t[2 * dp + dt][r] = val;
+                    amax = fmaxf(amax, fabsf(val));
+                }
+            }
+    }
     if (a.o8) {
         // int8 rows for the int8 fc: one scale per row and head = the maximum over both d_v halves (the partner wave's through LDS)
         amax = fmaxf(amax, __shfl_xor(amax, 32));

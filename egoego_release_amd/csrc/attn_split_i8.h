@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void attn_core_s_kernel(AttnLayerArgs a, At
     }
     const float sq = sqv[(wave & 3) * 32 + col];
     // ---- 3. S^T = K Q^T, softmax over keys: wave (query tile wave & 3, key half wave >> 2) — attn_layer_i8w_kernel phase 3
-    i32x4 ps1[2], ps2[2];
+    i32x4 ps1[2], ps2[2], ps3[2];
     {
         const int qt3 = wave & 3, kh = wave >> 2;
         I8Acc s[2];
@@ -541,10 +541,11 @@ __global__ __launch_bounds__(512, 2) void attn_core_s_kernel(AttnLayerArgs a, At
         if (hf == 0) psum[kh * 128 + qt3 * 32 + col] = sum;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            u32x4 s1, s2;
-            quant16(p[kt], I8_QMAX, s1, s2);
+            u32x4 s1, s2, s3;
+            quant_p(p[kt], s1, s2, s3);
             ps1[kt] = __builtin_bit_cast(i32x4, s1);
             ps2[kt] = __builtin_bit_cast(i32x4, s2);
+            ps3[kt] = __builtin_bit_cast(i32x4, s3);
         }
         // the probabilities of the four query tiles -> LDS over the Q image (every wave read its Q fragments before the barrier above)
 #pragma unroll
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(512, 2) void attn_core_s_kernel(AttnLayerArgs a, At
             char* dst = ring + (((wave & 3) * 4 + 2 * (wave >> 2) + kt) << 10) + lane * 16;
             *(i32x4*)dst = ps1[kt];
             *(i32x4*)(dst + 16384) = ps2[kt];
+            *(i32x4*)(dst + 32768) = ps3[kt];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the V^T image
@@ -559,48 +561,56 @@ __global__ __launch_bounds__(512, 2) void attn_core_s_kernel(AttnLayerArgs a, At
     // ---- 5. O^T = V^T P: wave (query tile qt, d_v half dvh) — attn_layer_i8w_kernel phase 5
     const int qt = wave & 3, dvh = wave >> 2;
     const int m = b * 128 + qt * 32 + col;
-    i32x4 pa1[4], pa2[4];
+    i32x4 pa1[4], pa2[4], pa3[4];  // all four key blocks of this wave's query tile, three slices (attn_layer_i8.h quant_p)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         const char* src = ring + ((qt * 4 + kb) << 10) + lane * 16;
         pa1[kb] = lds_frag(src);
         pa2[kb] = lds_frag(src + 16384);
+        pa3[kb] = lds_frag(src + 32768);
     }
-    const float oscale = (1.0f / (psum[qt * 32 + col] + psum[128 + qt * 32 + col])) * (256.0f / I8_QMAX);
-    I8Acc oa[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc_zero(oa[dt]);
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        i32x4 v1[4], v2[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const char* src = kv + (((dvh * 4 + dt) * 4 + kb) << 10) + lane * 16;
-            v1[dt] = lds_frag(src);
-            v2[dt] = lds_frag(src + AL_SLICE);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oa[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], pa1[kb], oa[dt].m, 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oa[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa2[kb], oa[dt].m, 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oa[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa1[kb], oa[dt].h, 0, 0, 0);
-    }
+    const float oscale = (1.0f / (psum[qt * 32 + col] + psum[128 + qt * 32 + col])) * (256.0f / P_QMAX);
     float t[4][16];
     float amax = 0.f;
+    // two d_v tiles at a time (three int32 accumulators per tile: the four at once would not leave room for their float results)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dp = 0; dp < 2; ++dp) {
+        PVAcc oa[2];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 s4 = *(const float4*)(sv + (dvh * 4 + dt) * 32 + 8 * gq + 4 * hf);
-            const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+        for (int dt = 0; dt < 2; ++dt) acc_zero(oa[dt]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float val = (float)i8_combine(oa[dt].h[4 * gq + c], oa[dt].m[4 * gq + c]) * (ss[c] * oscale);
-                t[dt][4 * gq + c] = val;
-                amax = fmaxf(amax, fabsf(val));
+        for (int kb = 0; kb < 4; ++kb) {
+            i32x4 v1[2], v2[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* src = kv + (((dvh * 4 + 2 * dp + dt) * 4 + kb) << 10) + lane * 16;
+                v1[dt] = lds_frag(src);
+                v2[dt] = lds_frag(src + AL_SLICE);
             }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oa[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], pa1[kb], oa[dt].m, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oa[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa1[kb], oa[dt].h, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oa[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa2[kb], oa[dt].m, 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oa[dt].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], pa3[kb], oa[dt].l, 0, 0, 0);
         }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 s4 = *(const float4*)(sv + (dvh * 4 + 2 * dp + dt) * 32 + 8 * gq + 4 * hf);
+                const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = 4 * gq + c;
+                    const float val = pv_value(oa[dt].h[r], oa[dt].m[r], oa[dt].l[r]) * (ss[c] * oscale);
+                    t[2 * dp + dt][r] = val;
+                    amax = fmaxf(amax, fabsf(val));
+                }
+            }
+    }
     if (a.o8) {
         amax = fmaxf(amax, __shfl_xor(amax, 32));
         if (hf == 0) red[dvh * 128 + qt * 32 + col] = amax;

@@ -351,7 +351,7 @@ class CondGaussianDiffusion(nn.Module):
         cands = (_lib.PREC_I8X3_FC, _lib.PREC_I8X3) if want == "auto" else (want,)
         forms = {"auto": (False, True), "always": (True,), "never": (False,)}[self.hip_int8_prep]
         probe = PrecisionProbe(self, tail=self.PROBE_TAIL)
-        errors, calib, pick = {}, None, None
+        errors, calib, pick, best = {}, None, None, None
         try:
             sd = probe.sd
             for prec in cands:
@@ -366,15 +366,20 @@ class CondGaussianDiffusion(nn.Module):
                         sd_s, row_shift, sd_u = sd, None, None
                     err, row_max = probe.error(sd_s, prec, row_shift)
                     errors[(prec, "prepared" if prepared else "as is")] = err
+                    cand = {"precision": prec, "sd": sd_s if prepared else None, "row_shift": row_shift, "sd_unshifted": sd_u, "prepared": prepared}
+                    if best is None or err < best[0]:
+                        best = (err, cand, row_max)
                     if err <= self.PROBE_LIMIT:
-                        pick = {"precision": prec, "sd": sd_s if prepared else None, "row_shift": row_shift, "sd_unshifted": sd_u, "prepared": prepared}
+                        pick = cand
                         break
                 if pick is not None:
                     break
         finally:
             probe.close()
+        explicit_best = want != "auto" and pick is None
         self.hip_precision_probe = {"errors": {f"{p} {f}": e for (p, f), e in errors.items()}, "limit": self.PROBE_LIMIT,
-                                    "row_max": row_max if pick is not None else None, "prepared": bool(pick and pick["prepared"])}
+                                    "row_max": row_max if pick is not None else (best[2] if explicit_best else None),
+                                    "prepared": bool(pick["prepared"] if pick else (explicit_best and best[1]["prepared"]))}
         if pick is not None:
             self._slot.envelope = row_max
             return pick
@@ -389,7 +394,8 @@ class CondGaussianDiffusion(nn.Module):
             f"hip_precision={want} differs from split-bf16 by more than {self.PROBE_LIMIT:.0e} on the probe batch for this checkpoint "
             f"({shown}; the limit is half the 1e-3 bar): it may leave the bar; set model.hip_precision = 'auto' or {_lib.PREC_BF16X3}",
             RuntimeWarning, stacklevel=4)
-        return plain
+        self._slot.envelope = best[2]
+        return best[1]  # the explicit precision is kept, in the packing that measured best
 
     @torch.no_grad()
     def _outlier_guard(self, eng, x, x_cond):

@@ -82,6 +82,22 @@ class Shim:
     def begin_forward(self):
         self.layer, self.ln_count = 0, 0
 
+    # the attention core's own int8 images (the kernels quantise Q and K per row and head, V per feature column over the window's keys,
+    # the un-normalised probabilities exp(s - rowmax) with the fixed scale 1 / 32639): torch.bmm is patched while a chain with any of these sites runs
+    def bmm(self, a, b):
+        if a.shape[-1] == 256 and b.shape[-2] == 256:  # Q [HB, L, 256] x K^T [HB, 256, L]
+            if self.on("q"):
+                a = quant15(a, dim=-1)
+            if self.on("k"):
+                b = quant15(b, dim=-2)
+        elif b.shape[-1] == 256:                        # P [HB, L, L] x V [HB, L, 256]
+            if self.on("p"):  # the kernels quantise exp(s - rowmax) in (0, 1] — the row's largest probability is exactly 1 there
+                pm = a.amax(-1, keepdim=True)
+                a = torch.round(a / pm * QMAX) / QMAX * pm
+            if self.on("v"):
+                b = quant15(b, dim=-2)
+        return self._bmm(a, b)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -112,6 +128,8 @@ def main():
     def chain(weights, sites, shift=None):
         shim = Shim(sites, shift)
         O.F = shim
+        shim._bmm = torch.bmm
+        torch.bmm = shim.bmm
         real_denoise = O.denoise
 
         x = nz["x_T"].clone()
@@ -120,6 +138,7 @@ def main():
                 shim.begin_forward()
                 x = O.p_sample(weights, sched, x, torch.full((B,), tv, dtype=torch.long), x_cond, nz["steps"][i])
         O.F = TF
+        torch.bmm = shim._bmm
         return x, shim.crest
 
     ref, crest = chain(sd, set())
@@ -232,6 +251,11 @@ def main():
     report("nearest weights + every activation site, LayerNorm rows mean-shifted", sdq, allsites, shift)
     report("GPTQ weights + every activation site, LayerNorm rows mean-shifted", sdg, allsites, shift)
     report("GPTQ weights + bias correction + every activation site, LayerNorm rows mean-shifted", sdgc, allsites, shift)
+    core = {("all", "q"), ("all", "k"), ("all", "v"), ("all", "p")}
+    report("GPTQ + shifted LayerNorm rows + every site + the attention core's Q, K, V, P images", sdg, allsites | core, shift)
+    for nm in ("q", "k", "v", "p"):
+        report(f"GPTQ + shifted LayerNorm rows + every site + only the {nm.upper()} image", sdg, allsites | {("all", nm)}, shift)
+    report("exact weights and rows, only the attention core's Q, K, V, P images", sd, core)
     _, cr = chain(sd, set())
     print("LayerNorm row crest after the mean shift:", {f"L{k[0]}.{k[1]}": round(float(((torch.cat(rows[(k[0], 'w_1')] if k[1] == 'ln1' else (rows[(k[0] + 1, 'qkv')] if k[0] < 3 else rows[('out', 'linear_out')]), 0) - v).abs().amax(-1) / (torch.cat(rows[(k[0], 'w_1')] if k[1] == 'ln1' else (rows[(k[0] + 1, 'qkv')] if k[0] < 3 else rows[('out', 'linear_out')]), 0) - v).pow(2).mean(-1).sqrt()).max()), 1) for k, v in shift.items()})
     report("weights + bias correction + every activation site", sdc, {("all", "ln1"), ("all", "ln2"), ("all", "o"), ("all", "hid")})

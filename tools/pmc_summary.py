@@ -18,6 +18,8 @@ N_XCD = 8      # GRBM_GUI_ACTIVE is summed over the 8 XCDs
 def short(name):
     m = re.match(r"void (\w+)<", name)
     base = m.group(1) if m else name.split("(")[0]
+    if base == "tail_kernel":  # its template arguments select different kernels (4- / 8-wave, LDS-resident FFN operands, ...): keep them
+        base = re.match(r"void (tail_kernel<[^>]*>)", name).group(1).replace(" ", "")
     for tag in ("EpiEmbed", "EpiOut", "EpiQK") + (("EpiTiled", "EpiResLN") if "layer_tail" not in name else ()):  # (layer_tail*: one tag per kernel)
         if tag in name:
             base += ":" + tag

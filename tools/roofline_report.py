@@ -16,7 +16,7 @@ ALG = {  # kernel tag -> (what, algorithmic FLOPs per launch, algorithmic HBM by
                              2 * B * L * DM + 2 * B * L * HD + 2 * 3 * HD * DM),
     # precision 9: the attention output (2 B x 1024), the residual rows in and the layer's rows out (2 B x 512 each) per token; the
     # LayerNorm-1 rows and the hidden rows stay in LDS
-    "tail_kernel|layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; precision 9: all three contractions on int8 slices, FFN operands resident in LDS; int8 peak)",
+    "tail_kernel<1,true,true,true,4,true>|layer_tail": ("fc+LN, FFN-1, FFN-2+LN (one layer; precision 9: all three contractions on int8 slices, FFN operands resident in LDS; int8 peak)",
                                B * L * (2 * HD * DM + 4 * DM * DM), 2 * B * L * (HD + DM + DM) + 2.1e6),
     # the split-bf16 operand (x | x_cond, 4 B per value) in, int8 rows (2 B per value) out
     "EpiEmbed": ("embed GEMM + time token + pos-emb (split-bf16 in, int8 rows out)", 2 * B * T * 2 * D * DM, 4 * B * T * 2 * D + 2 * B * L * DM),
@@ -36,7 +36,7 @@ def main():
     rows = []
     for tag, (what, flops, abytes) in ALG.items():
         tags = tag.split("|")
-        st = next(r for r in stats if any(t in r["Name"] for t in tags))
+        st = next(r for r in stats if any(t in r["Name"].replace(" ", "") for t in tags))
         us = float(st["AverageNs"]) / 1e3
         tr = next((v for k, v in traffic.items() if any(t in k for t in tags)), None)
         pm = next((v for k, v in pmc.items() if any(t in k for t in tags)), {})
