@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     dma_k_half(1, 1);
 
     // ---- S^T = K Q^T over the two d_k halves, softmax over keys (TM:76-82), P * s_v quantised per query
-    i32x4 ps1[KT], ps2[KT];
+    i32x4 ps1[KT], ps2[KT], ps3[KT];  // three slices (attn_layer_i8.h quant_p): small probabilities keep their relative precision
     float oscale;
     {
         I8Acc s[KT];
@@ -343,14 +343,17 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
             }
         sum += __shfl_xor(sum, 32);
         pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
-        const float pinv = pmax > 0.f ? I8_QMAX / pmax : 0.f;
-        oscale = (1.0f / sum) * (pmax > 0.f ? pmax / I8_QMAX : 0.f) * 256.0f;
+        const float pinv = pmax > 0.f ? 1.0f / pmax : 0.f;
+        oscale = (1.0f / sum) * (pmax / P_QMAX) * 256.0f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            u32x4 s1, s2;
-            quant16(p[kt], pinv, s1, s2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[kt][r] = fminf(p[kt][r] * pinv, 1.0f);
+            u32x4 s1, s2, s3;
+            quant_p(p[kt], s1, s2, s3);
             ps1[kt] = __builtin_bit_cast(i32x4, s1);
             ps2[kt] = __builtin_bit_cast(i32x4, s2);
+            ps3[kt] = __builtin_bit_cast(i32x4, s3);
         }
     }
 
@@ -364,48 +367,55 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
         if (dvh == 0) wait_counts<NPIECE, 15>(); else wait_counts<0, 15>();
         __syncthreads();
         const char* img = kv + dvh * BUF;
-        I8Acc o[4];
+        // two d_v tiles at a time: three accumulators per tile (PVAcc) x four tiles would not fit beside the queries' P slices and the
+        // first half's waiting values
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc_zero(o[dt]);
+        for (int dp = 0; dp < 2; ++dp) {
+            PVAcc o[2];
 #pragma unroll
-        for (int kb = 0; kb < KT; ++kb) {
-            i32x4 v1[4], v2[4];
+            for (int dt = 0; dt < 2; ++dt) acc_zero(o[dt]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const char* src = img + ((dt * KT + kb) << 10) + lane * 16;
-                v1[dt] = lds_frag(src);
-                v2[dt] = lds_frag(src + HALF);
-            }
+            for (int kb = 0; kb < KT; ++kb) {
+                i32x4 v1[2], v2[2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], ps1[kb], o[dt].m, 0, 0, 0);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps2[kb], o[dt].m, 0, 0, 0);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps1[kb], o[dt].h, 0, 0, 0);
-        }
-        if (a.o8) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = (float)i8_combine(o[dt].h[r], o[dt].m[r]) * oscale;
-                    t8[dvh * 4 + dt][r] = v;
-                    amax = fmaxf(amax, fabsf(v));
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* src = img + (((2 * dp + dt) * KT + kb) << 10) + lane * 16;
+                    v1[dt] = lds_frag(src);
+                    v2[dt] = lds_frag(src + HALF);
                 }
-        } else if (active) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int tile = dvh * 4 + dt;
+                for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], ps1[kb], o[dt].m, 0, 0, 0);
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    float t[8];
+                for (int dt = 0; dt < 2; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps1[kb], o[dt].h, 0, 0, 0);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = (float)i8_combine(o[dt].h[8 * jj + e], o[dt].m[8 * jj + e]) * oscale;
-                    u32x4 hi, lo;
-                    split8(t, hi, lo);
-                    const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
-                    *(u32x4*)(a.o + idx) = hi;
-                    *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                for (int dt = 0; dt < 2; ++dt) o[dt].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps3[kb], o[dt].l, 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps2[kb], o[dt].m, 0, 0, 0);
+            }
+            if (a.o8) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = pv_value(o[dt].h[r], o[dt].m[r], o[dt].l[r]) * oscale;
+                        t8[dvh * 4 + 2 * dp + dt][r] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+            } else if (active) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int tile = dvh * 4 + 2 * dp + dt;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        float t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t[e] = pv_value(o[dt].h[8 * jj + e], o[dt].m[8 * jj + e], o[dt].l[8 * jj + e]) * oscale;
+                        u32x4 hi, lo;
+                        split8(t, hi, lo);
+                        const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
+                        *(u32x4*)(a.o + idx) = hi;
+                        *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                    }
                 }
             }
         }

@@ -157,7 +157,9 @@ def make_motion_windows(B, T, seed=0, device="cpu", d_feats=198):
     K[..., 0, 1], K[..., 0, 2], K[..., 1, 0] = -ax[..., 2], ax[..., 1], ax[..., 2]
     K[..., 1, 2], K[..., 2, 0], K[..., 2, 1] = -ax[..., 0], -ax[..., 1], ax[..., 0]
     eye = torch.eye(3, device=dev).expand(B, T, 22, 3, 3)
-    Rl = eye + torch.sin(ang)[..., None] * K + (1 - torch.cos(ang))[..., None] * (K @ K)  # Rodrigues
+    # batched matmul in pieces: one call over B*T*22 > 2^24 matrices faults inside the BLAS on this stack (4096 x 196 x 22, measured)
+    KK = torch.cat([k @ k for k in K.split(512)])
+    Rl = eye + torch.sin(ang)[..., None] * K + (1 - torch.cos(ang))[..., None] * KK  # Rodrigues
     step = 0.01 * rnd(B, T, 3)
     step = torch.nn.functional.avg_pool1d(step.transpose(1, 2), 9, 1, 4, count_include_pad=False).transpose(1, 2)
     root = torch.cumsum(step, dim=1) * 3.0

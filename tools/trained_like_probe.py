@@ -50,9 +50,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--ckpt", default=None)
     ap.add_argument("--chain", type=int, default=50)
+    ap.add_argument("--window", type=int, default=120)
     args = ap.parse_args()
     warnings.simplefilter("ignore")
-    T, B = 120, 4
+    T, B = args.window, 4
     cfg = ModelConfig(max_timesteps=T + 1)
     if args.ckpt:
         sd = torch.load(args.ckpt, map_location="cpu")["model"]
@@ -72,6 +73,8 @@ def main():
         m = CondGaussianDiffusion(**cfg.ctor_kwargs())
         m.load_state_dict(sd, strict=False)
         m.hip_precision = prec
+        if prec != "auto":
+            m.hip_int8_prep = "never"
         m = m.to(dev)
         m.denoise_fn.eval()
         models[prec] = m
