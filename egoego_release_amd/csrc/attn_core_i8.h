@@ -29,6 +29,7 @@ struct Qkv8Out {
     float qscale;          // 1 / sqrt(d_k)
     int Lp, KT, H, HD, Mvalid;
     int Lr;                // token rows per window in the ROW space (a multiple of 16, <= Lp = 32 KT): window b owns rows b Lr .. b Lr + Lr - 1
+    EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][8] phase timestamps or nullptr (tools/long_window_trace.py)
 };
 
 // Quantise 16 values, each with its own inverse scale, into the two slices (cf. common.h quant16).
@@ -59,6 +60,12 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
     const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
     const int f0 = fblk * 256 + wf * 64, t0 = tblk * 64;
     const int which = fblk * 256 / o.HD, h = (fblk * 256 % o.HD) >> 8;  // 0 = Q, 1 = K, 2 = V; head
+    EG_DBG(unsigned long long* tr = o.trace ? o.trace + 131072 + (size_t)blockIdx.x * 8 : nullptr;)
+    auto mark = [&](int i) {
+        EG_DBG(if (tr && threadIdx.x == 0) tr[i] = wall_clock64();)
+        (void)i;
+    };
+    mark(0);
     const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
     float* red = (float*)smem;  // [4][64] cross-wave maxima; the main loop's ring is dead when it is used
     // the block's parameters (weight row scales and biases of its 256 features, row scales of its 64 tokens) staged in LDS behind the
@@ -75,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
     if (which < 2) {
         // ---- Q_h / K_h: lane owns a token; one scale per row; int8 image [token tile][d_k block]
         GemmBody<Q8K, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        mark(1);
         const float sc = which == 0 ? o.qscale : 1.0f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -98,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             if (hf == 0) red[wf * 64 + j * 32 + col] = amax;
         }
         __syncthreads();
+        mark(2);
         int8_t* dst8 = which == 0 ? o.q8 : o.k8;
         float* dsts = which == 0 ? o.sq : o.sk;
 #pragma unroll
@@ -128,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
         // (maximum over the head's 256 features: two tiles in-lane, 32 lanes by shuffles, four waves through LDS);
         // stored transposed [d_v tile][key block]
         GemmBody<Q8V, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        mark(1);
         float tmax[2][16];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
                 if (col == 0) red[wf * 64 + j * 32 + mfma32_row(r, hf)] = m;
             }
         __syncthreads();
+        mark(2);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float inv[16], rm[16];
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             }
         }
     }
+    mark(3);
 }
 
 struct AttnCore8Args {
@@ -210,6 +222,7 @@ struct AttnCore8Args {
     int8_t* o8;
     size_t o8_plane;
     float* o_scale;
+    EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][8] phase timestamps or nullptr
 };
 
 // The K image (d_k halves) and the V^T image (d_v halves) pass through two LDS buffers of KT * 8 KiB x 2 slices each, the next
@@ -231,6 +244,15 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     const bool tile_active = qt_raw < KT;
     const int qt = tile_active ? qt_raw : KT - 1;
     const bool active = tile_active && qt * 32 + col < a.Lr;  // per lane: the last query tile may reach beyond the window's rows
+    EG_DBG(unsigned long long* tr = a.trace ? a.trace + 131072 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;)
+    auto mark = [&](int i) {
+        EG_DBG(if (tr && threadIdx.x == 0) {
+            tr[i] = wall_clock64();
+            if (i == 1 || i == 2) tr[5 + i] = __builtin_readcyclecounter();  // shader cycles over the S^T phase
+        })
+        (void)i;
+    };
+    mark(0);
     // (resources based at THIS (window, head)'s image, so that the 32-bit offsets — slice stride + a few hundred KiB — stay far below
     // the 2^31 - 1 bytes a buffer resource can span whatever the batch)
     const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.k8 + (((size_t)bh * KT * 8) << 10)), 0, 0x7fffffff, 0x00020000);
@@ -258,6 +280,13 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
                                                      lane * 16, src, 0, 0);
         }
     };
+    auto dma_v_piece = [&](int hh, int buf, int n) {
+        const int pc = n * 4 + wave;
+        const int sl = pc / (KT * 4), blk = pc - sl * KT * 4;
+        const unsigned src = (unsigned)(sl * a.plane) + (unsigned)((4 * hh * KT + blk) << 10);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + sl * HALF + (blk << 10)), 16,
+                                                 lane * 16, src, 0, 0);
+    };
     dma_k_half(0, 0);
     for (int i = threadIdx.x; i < KT * 32; i += 256) {
         sk[i] = a.sk[(size_t)bh * a.Lp + i];
@@ -273,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     const float sq = a.sq[(size_t)bh * a.Lp + qt * 32 + col];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    mark(1);
     dma_k_half(1, 1);
 
     // ---- S^T = K Q^T over the two d_k halves, softmax over keys (TM:76-82), P * s_v quantised per query
@@ -282,30 +312,50 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
         I8Acc s[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc_zero(s[kt]);
+        // One unit = one d_k block x a PAIR of key tiles: 4 fragment reads, 6 MFMAs (the second MFMA into an `m` accumulator four
+        // MFMAs behind the first).  The fragments of unit u + 2 are requested before unit u's MFMAs (a ring of three): with one wave
+        // per SIMD nothing else covers the LDS latency, and hipcc left to itself sinks every read to its use (round 4 trace: 6.4 us
+        // for 2.6 us of MFMAs).  Integer accumulation: any order gives the same bits.
+        constexpr int NU = (KT + 1) / 2, NS = 4 * NU;
+        i32x4 f[3][4];
+        auto load_unit = [&](const char* img, int u, i32x4(&d)[4]) {
+            const int i = u / NU, kt0 = 2 * (u % NU);
+            const char* src = img + ((kt0 * 4 + i) << 10) + lane * 16;
+            d[0] = lds_frag(src);
+            d[1] = lds_frag(src + HALF);
+            if (kt0 + 1 < KT) {
+                d[2] = lds_frag(src + 4096);
+                d[3] = lds_frag(src + 4096 + HALF);
+            }
+        };
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const char* img = kv + hh * BUF;
+            load_unit(img, 0, f[0]);
+            if (NS > 1) load_unit(img, 1, f[1]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                i32x4 k1[KT], k2[KT];
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const char* src = img + ((kt * 4 + i) << 10) + lane * 16;
-                    k1[kt] = lds_frag(src);
-                    k2[kt] = lds_frag(src + HALF);
-                }
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k2[kt], qs1[4 * hh + i], s[kt].m, 0, 0, 0);
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) s[kt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs2[4 * hh + i], s[kt].m, 0, 0, 0);
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) s[kt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(k1[kt], qs1[4 * hh + i], s[kt].h, 0, 0, 0);
+            for (int u = 0; u < NS; ++u) {
+                if (u + 2 < NS) load_unit(img, u + 2, f[(u + 2) % 3]);
+                // second d_k half: the first V^T half streams into the buffer the barrier below freed, one piece per unit
+                if (hh == 1 && u < NPIECE) dma_v_piece(0, 0, u);
+                const int i = u / NU, kt0 = 2 * (u % NU);
+                const bool two = kt0 + 1 < KT;
+                const i32x4 q1 = qs1[4 * hh + i], q2 = qs2[4 * hh + i];
+                i32x4(&c)[4] = f[u % 3];
+                s[kt0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[1], q1, s[kt0].m, 0, 0, 0);
+                if (two) s[kt0 + 1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[3], q1, s[kt0 + 1].m, 0, 0, 0);
+                s[kt0].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], q1, s[kt0].h, 0, 0, 0);
+                if (two) s[kt0 + 1].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], q1, s[kt0 + 1].h, 0, 0, 0);
+                s[kt0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], q2, s[kt0].m, 0, 0, 0);
+                if (two) s[kt0 + 1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], q2, s[kt0 + 1].m, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // the buffer every wave has finished with takes the next V half; the second K half must have landed
             if (hh == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            dma_v_half(hh, hh);
+            if (hh == 1) dma_v_half(1, 1);
         }
+        mark(2);
         float p[KT][16];
         float mx = -INFINITY;
         const float sq256 = sq * 256.0f * 1.44269504088896f;  // logits in units of log2(e): softmax through v_exp_f32
@@ -343,83 +393,93 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
             }
         sum += __shfl_xor(sum, 32);
         pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
-        const float pinv = pmax > 0.f ? 1.0f / pmax : 0.f;
-        oscale = (1.0f / sum) * (pmax / P_QMAX) * 256.0f;
+        // q = rint(p * pk) <= P_QMAX for every p <= pmax: the quarter unit of slack covers the rounding of pk and of the product
+        const float pk = pmax > 0.f ? (P_QMAX - 0.25f) / pmax : 0.f;
+        oscale = (1.0f / sum) * (pmax / (P_QMAX - 0.25f)) * 256.0f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[kt][r] = fminf(p[kt][r] * pinv, 1.0f);
             u32x4 s1, s2, s3;
-            quant_p(p[kt], s1, s2, s3);
+            quant_p(p[kt], pk, s1, s2, s3);
             ps1[kt] = __builtin_bit_cast(i32x4, s1);
             ps2[kt] = __builtin_bit_cast(i32x4, s2);
             ps3[kt] = __builtin_bit_cast(i32x4, s3);
         }
     }
 
+    mark(3);
     // ---- O^T = V^T P (TM:83-88) per d_v half, heads merged on store
     const int m = b * a.Lr + qt * 32 + col;
-    float t8[8][16];  // int8 output: the first half's values wait for the row maximum over the head's 256 features
+    float t8[8][16];  // int8 output: the values wait for the row maximum over the head's 256 features
     float amax = 0.f;
+    // both V^T halves were requested before the softmax: one wait, one barrier, then 4 groups (d_v half x tile pair) x KT key blocks
+    // of 4 fragment reads + 8 MFMAs, the reads two units ahead like above
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        constexpr int NPV = 4 * KT;
+        i32x4 f[3][4];
+        auto load_unit = [&](int u, i32x4(&d)[4]) {
+            const int g = u / KT, kb = u - g * KT, dvh = g >> 1, dp = g & 1;
 #pragma unroll
-    for (int dvh = 0; dvh < 2; ++dvh) {
-        // this half has landed: all pieces of half 0 were issued before those of half 1 (loads return in order)
-        if (dvh == 0) wait_counts<NPIECE, 15>(); else wait_counts<0, 15>();
-        __syncthreads();
-        const char* img = kv + dvh * BUF;
-        // two d_v tiles at a time: three accumulators per tile (PVAcc) x four tiles would not fit beside the queries' P slices and the
-        // first half's waiting values
-#pragma unroll
-        for (int dp = 0; dp < 2; ++dp) {
-            PVAcc o[2];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) acc_zero(o[dt]);
-#pragma unroll
-            for (int kb = 0; kb < KT; ++kb) {
-                i32x4 v1[2], v2[2];
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const char* src = img + (((2 * dp + dt) * KT + kb) << 10) + lane * 16;
-                    v1[dt] = lds_frag(src);
-                    v2[dt] = lds_frag(src + HALF);
-                }
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v2[dt], ps1[kb], o[dt].m, 0, 0, 0);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps1[kb], o[dt].h, 0, 0, 0);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps3[kb], o[dt].l, 0, 0, 0);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(v1[dt], ps2[kb], o[dt].m, 0, 0, 0);
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* src = kv + dvh * BUF + (((2 * dp + dt) * KT + kb) << 10) + lane * 16;
+                d[2 * dt] = lds_frag(src);
+                d[2 * dt + 1] = lds_frag(src + HALF);
             }
-            if (a.o8) {
+        };
+        load_unit(0, f[0]);
+        load_unit(1, f[1]);
+        PVAcc o[2];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+        for (int u = 0; u < NPV; ++u) {
+            const int g = u / KT, kb = u - g * KT;
+            if (kb == 0) {
+                acc_zero(o[0]);
+                acc_zero(o[1]);
+            }
+            if (u + 2 < NPV) load_unit(u + 2, f[(u + 2) % 3]);
+            i32x4(&c)[4] = f[u % 3];
+            o[0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[1], ps1[kb], o[0].m, 0, 0, 0);
+            o[1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[3], ps1[kb], o[1].m, 0, 0, 0);
+            o[0].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps1[kb], o[0].h, 0, 0, 0);
+            o[1].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps1[kb], o[1].h, 0, 0, 0);
+            o[0].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps3[kb], o[0].l, 0, 0, 0);
+            o[1].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps3[kb], o[1].l, 0, 0, 0);
+            o[0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps2[kb], o[0].m, 0, 0, 0);
+            o[1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps2[kb], o[1].m, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb == KT - 1) {
+                if (a.o8) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = pv_value(o[dt].h[r], o[dt].m[r], o[dt].l[r]) * oscale;
-                        t8[dvh * 4 + 2 * dp + dt][r] = v;
-                        amax = fmaxf(amax, fabsf(v));
-                    }
-            } else if (active) {
+                    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int tile = dvh * 4 + 2 * dp + dt;
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = pv_value(o[dt].h[r], o[dt].m[r], o[dt].l[r]) * oscale;
+                            t8[2 * g + dt][r] = v;
+                            amax = fmaxf(amax, fabsf(v));
+                        }
+                } else if (active) {
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        float t[8];
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int tile = 2 * g + dt;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) t[e] = pv_value(o[dt].h[8 * jj + e], o[dt].m[8 * jj + e], o[dt].l[8 * jj + e]) * oscale;
-                        u32x4 hi, lo;
-                        split8(t, hi, lo);
-                        const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
-                        *(u32x4*)(a.o + idx) = hi;
-                        *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                        for (int jj = 0; jj < 2; ++jj) {
+                            float t[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t[e] = pv_value(o[dt].h[8 * jj + e], o[dt].m[8 * jj + e], o[dt].l[8 * jj + e]) * oscale;
+                            u32x4 hi, lo;
+                            split8(t, hi, lo);
+                            const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
+                            *(u32x4*)(a.o + idx) = hi;
+                            *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                        }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    mark(4);
     if (a.o8 && active) {
         amax = fmaxf(amax, __shfl_xor(amax, 32));
         const float inv = amax > 0.f ? I8_QMAX / amax : 0.f;
@@ -433,4 +493,5 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
             *(u32x4*)(a.o8 + a.o8_plane + idx) = s2;
         }
     }
+    mark(5);
 }

@@ -71,12 +71,14 @@ EG_D void acc_zero(PVAcc& c) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) c.h[r] = c.m[r] = c.l[r] = 0;
 }
-// 16 probabilities in [0, 1] -> three slices of 16 bytes.  q = rint(p * P_QMAX) < 2^23 (v_rndne + v_cvt: the float-adder trick of
-// common.h quant16 stops at 2^22); byte 0 of q is a3, byte 1 of q + 128 is a2, byte 2 of q + 128 + 32768 is a1.
-EG_D void quant_p(const float v[16], u32x4& s1, u32x4& s2, u32x4& s3) {
+// 16 values v with 0 <= v * k <= P_QMAX -> three slices of 16 bytes.  q = rint(v * k) < 2^23 sits in the mantissa of v * k + 2^23 (one
+// fma; the values are not negative, so the adder trick of common.h quant16 reaches one bit further than there); byte 0 of q is a3,
+// byte 1 of q + 128 is a2, byte 2 of q + 128 + 32768 is a1 (the float's exponent byte is never selected, and no carry reaches it:
+// q + 32896 <= 0x7fffff).
+EG_D void quant_p(const float v[16], float k, u32x4& s1, u32x4& s2, u32x4& s3) {
     uint32_t q[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) q[i] = (uint32_t)(int)__builtin_rintf(v[i] * P_QMAX);
+    for (int i = 0; i < 16; ++i) q[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[i], k, 8388608.0f));
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const uint32_t a = q[4 * w], b = q[4 * w + 1], c = q[4 * w + 2], d = q[4 * w + 3];

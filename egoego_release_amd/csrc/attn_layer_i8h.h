@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8h_kernel(AttnLayerArgs a)
         s1 += __shfl_xor(s1, 32);
         if (hf == 0) psum[kt * 64 + qt * 32 + col] = s1;  // read in phase 5, behind the V projection's barriers
         u32x4 u1, u2, u3;
-        quant_p(p, u1, u2, u3);
+        quant_p(p, P_QMAX, u1, u2, u3);
         ps1 = __builtin_bit_cast(i32x4, u1);
         ps2 = __builtin_bit_cast(i32x4, u2);
         ps3 = __builtin_bit_cast(i32x4, u3);

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             u32x4 s1, s2, s3;
-            quant_p(p[kt], s1, s2, s3);
+            quant_p(p[kt], P_QMAX, s1, s2, s3);
             ps1[kt] = __builtin_bit_cast(i32x4, s1);
             ps2[kt] = __builtin_bit_cast(i32x4, s2);
             ps3[kt] = __builtin_bit_cast(i32x4, s3);

@@ -750,7 +750,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     ProfScope ps(c, EGOEGO_K_QKV, s);
                     QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, rows / 64, 2 * HD / BLK_A_F};
                     Qkv8Out qo{(int8_t*)w.Q, (int8_t*)w.K, (int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, L.b_qkv,
-                               1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid, g.Lr};
+                               1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid, g.Lr EG_DBG(, g_trace)};
                     static DevOnce once;
                     if (once.pending()) {
                         HIP_TRY(allow_smem(qkv_i8q_kernel, Q8K::SMEM_BYTES + 4096));
@@ -764,6 +764,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     ProfScope ps(c, EGOEGO_K_ATTN, s);
                     AttnCore8Args ca{(const int8_t*)w.Q, (const int8_t*)w.K, (const int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, w.O, w.o_plane,
                                      HD / 16, H, g.L, g.Lp, g.Lr};
+                    EG_DBG(ca.trace = g_trace ? g_trace + 90112 : nullptr;)
                     if (fc8) {
                         ca.o8 = w.O8; ca.o8_plane = w.o_plane; ca.o_scale = w.O_scale;
                     }

@@ -35,8 +35,8 @@ def trained():
     return sd, info
 
 
-def _build(sd, prec="auto", **knobs):
-    cfg = ModelConfig(max_timesteps=T + 1)
+def _build(sd, prec="auto", window=T, **knobs):
+    cfg = ModelConfig(max_timesteps=window + 1)
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
     m.load_state_dict(sd, strict=False)
     m.hip_precision = prec
@@ -138,6 +138,52 @@ def test_trained_like_forward_and_chain_against_oracle(trained):
         want = O.denoise(sd, torch.cat((xq, xc), -1), tv, padding_mask=pm)
     got = mp.denoise(xq.cuda(), tv.cuda(), xc.cuda(), padding_mask=pm.cuda()).cpu()
     assert float((got - want).abs().max()) < POSE_TOL, float((got - want).abs().max())
+
+
+def test_trained_like_long_window_against_oracle():
+    """The same at BASELINE configs[3]'s window (T = 196: `qkv_i8q_kernel` + `attn_core_i8_kernel<7>`, V scaled per key, the
+    probabilities' scale per query): a checkpoint trained at that length, what `auto` picks for it, one forward and a 50-step
+    chain against the oracle.  (Round 4: with two-slice probabilities in the long-window core `auto`'s pick ended this chain
+    8.7e-4 from split-bf16 although its probe said 3.5e-4; with three slices 3.6e-4 / 1.7e-4.)"""
+    from make_trained_like_checkpoint import train_like
+    W, B, S = 196, 2, 50
+    sd, info = train_like(steps=3000, seed=0, device="cuda", T=W)
+    assert info["loss_last"] < 0.6 * info["loss_first"], info
+    sd = {k: v for k, v in sd.items() if k.startswith("denoise_fn.")}
+    data = make_motion_windows(B, W, seed=4243)
+    mask = head_condition_mask(data.shape)
+    g = torch.Generator().manual_seed(78)
+    eps = torch.randn(data.shape, generator=g)
+    xc = data * (1 - mask) + mask * torch.randn(data.shape, generator=g)
+    sched = O.make_schedule(1000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        models = {"auto": _build(sd, window=W), _lib.PREC_BF16X3: _build(sd, _lib.PREC_BF16X3, window=W, hip_int8_prep="never"),
+                  "9 as is": _build(sd, _lib.PREC_I8X3_FC, window=W, hip_int8_prep="never")}
+        models["auto"].hip_engine()
+    print("T=196 trained-like:", info, "auto picked", models["auto"].hip_precision_used, models["auto"].hip_precision_probe)
+    t = torch.full((B,), 500, dtype=torch.long)
+    x = sched["sqrt_alphas_cumprod"][500] * data + sched["sqrt_one_minus_alphas_cumprod"][500] * eps
+    with torch.no_grad():
+        want = O.denoise(sd, torch.cat((x, xc), -1), t)
+    errs = {p: float((m.denoise(x.cuda(), t.cuda(), xc.cuda()).cpu() - want).abs().max()) for p, m in models.items()}
+    print("t=500 forward errors", errs)
+    assert errs["auto"] < POSE_TOL and errs[_lib.PREC_BF16X3] < POSE_TOL, errs
+    nz = {"x_T": torch.randn(data.shape, generator=g), "cond": torch.randn(data.shape, generator=g),
+          "steps": torch.randn(S, *data.shape, generator=g)}
+    x = nz["x_T"].clone()
+    x_cond = data * (1 - mask) + mask * nz["cond"]
+    with torch.no_grad():
+        for i, tv in enumerate(reversed(range(S))):
+            x = O.p_sample(sd, sched, x, torch.full((B,), tv, dtype=torch.long), x_cond, nz["steps"][i])
+    errs = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for p, m in models.items():
+            m.num_timesteps = S
+            errs[p] = float((m.sample(data.cuda(), mask.cuda(), noise=nz).cpu() - x).abs().max())
+    print(f"{S}-step chain errors", errs)
+    assert errs["auto"] < POSE_TOL and errs[_lib.PREC_BF16X3] < POSE_TOL, errs
 
 
 def test_runtime_outlier_guard_trips_on_massive_features_and_steps_down():

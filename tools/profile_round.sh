@@ -17,15 +17,15 @@ EGOEGO_FORCE_COLLECTIVE=1 python3 bench.py --gpus 1 --steps 100 --warmup 10 --no
 python3 bench.py --steps 200 --warmup 10 --weights trained-like --no-cpu-baseline > $O/bench_b256_t120_trained_like.json 2>> $O/bench.err
 python3 bench.py --steps 200 --warmup 10 --weights trained-like --precision 3 --no-cpu-baseline > $O/bench_b256_t120_trained_like_p3.json 2>> $O/bench.err
 python3 tools/step_times.py --steps 100 --batches 1,16,24,32,64,128,256 --windows 120,196 --api > $O/step_times.jsonl 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 bench.py --steps 20 --warmup 3 --precision 9 --no-probe --no-cpu-baseline > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b32 -o stats -- python3 bench.py --steps 50 --warmup 3 --batch 32 --precision 9 --no-probe --no-cpu-baseline > $O/stats_b32.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_t196 -o stats -- python3 bench.py --steps 20 --warmup 3 --window 196 --precision 9 --no-probe --no-cpu-baseline > $O/stats_t196.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_a -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_a.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_b -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_b.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_c.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 bench.py --steps 20 --warmup 3 --precision 9 --no-probe --no-cpu-baseline > $O/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b32 -o stats -- python3 bench.py --steps 50 --warmup 3 --batch 32 --precision 9 --no-probe --no-cpu-baseline > $O/stats_b32.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_t196 -o stats -- python3 bench.py --steps 20 --warmup 3 --window 196 --precision 9 --no-probe --no-cpu-baseline > $O/stats_t196.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_a -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_a.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_b -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_b.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_c.log 2>&1
 # calibration of FETCH_SIZE / WRITE_SIZE on known-byte kernels of this library's access shapes (tools/microbench/fetch_calib.hip)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_f -o pmc -- ./tools/microbench/_bin/fetch_calib > $O/calib_f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_w -o pmc -- ./tools/microbench/_bin/fetch_calib > $O/calib_w.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_f -o pmc -- ./tools/microbench/_bin/fetch_calib > $O/calib_f.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_w -o pmc -- ./tools/microbench/_bin/fetch_calib > $O/calib_w.log 2>&1
 # keep what travels back small: only the summaries
 find $O -name "*_kernel_stats.csv" -o -name "*counter_collection.csv" | head -30 > $O/files.txt
 find $O \( -name "*.db" -o -name "*_kernel_trace.csv" -o -name "*agent_info.csv" \) -delete
