@@ -218,280 +218,362 @@ struct AttnCore8Args {
     size_t o_plane;
     int HD16, H, L, Lp;
     int Lr;     // token rows per window in the row space (<= Lp); query l of window b is row b Lr + l
-    // o8 != nullptr: O as int8 slices with one scale per row and head (see AttnLayerArgs)
+    // kernel template O8: O as int8 slices with one scale per row and head (see AttnLayerArgs), else split-bf16 into `o`
     int8_t* o8;
     size_t o8_plane;
     float* o_scale;
-    EG_DBG(unsigned long long* trace;)  // perf-debug build: [grid][8] phase timestamps or nullptr
+    int BH;     // (window, head) pairs of the launch; the grid is min(BH * ceil(KT / 4), compute units) persistent workgroups
+    EG_DBG(unsigned long long* trace;)  // perf-debug build: [item][8] phase timestamps or nullptr
 };
 
-// The K image (d_k halves) and the V^T image (d_v halves) pass through two LDS buffers of KT * 8 KiB x 2 slices each, the next
-// half requested while the current one is multiplied: only the first K half is waited for with nothing to do.  S accumulates
+// The K image (d_k halves) and the V^T image (d_v halves) pass through two LDS buffers of KT * 8 KiB x 2 slices each.  S accumulates
 // over the two d_k halves in the same int32 accumulators (the row scales of K and Q cover the whole d_k).
-template <int KT>
+//
+// PERSISTENT workgroups (round 4).  An item = one (window, head, block of 4 query tiles); a workgroup walks items lid, lid + grid, ...
+// and requests the NEXT item's operands while the current one computes: its Q fragments (64 registers, dead after S^T) and scales
+// before the softmax, its first K half into buffer 0 the moment the PV phase is done with the first V^T half, its second K half
+// into buffer 1 after the PV phase.  The round-4 trace of the one-item-per-workgroup form (one wave per SIMD: nothing else on
+// the CU to cover a wait) showed 5.7 of a workgroup's 26 us waiting for the first 120 KB (K half + Q: the whole chip starts a
+// round at once and gets ~11 B/clk per CU) and the second K half arriving behind the first half's MFMAs.  Every wait is a full
+// vmcnt(0): what is waited for was requested a phase earlier.  Items are computed exactly as before: same bits.
+template <int KT, bool O8>
 __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
     constexpr int HALF = KT * 4 * 1024;  // bytes of one slice of half an image (4 of the 8 d blocks x KT tiles)
     constexpr int BUF = 2 * HALF;        // one buffer: both slices of a half image
+    constexpr int NQB = (KT + 3) / 4;    // query blocks (4 tiles, one per wave) per (window, head)
+    constexpr int NPIECE = KT * 8 / 4;   // 1-KiB pieces of a half image (both slices) per wave: KT*4 blocks x 2 slices / 4 waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kv = smem;                           // [2 buffers][slice][half image]
-    float* sk = (float*)(smem + 2 * BUF);      // [KT*32] key scales of K
-    float* sv = sk + KT * 32;                  // [KT*32] key scales of V
-    const int bh = (int)blockIdx.y, qb = (int)blockIdx.x;
-    const int b = bh / a.H, h = bh - b * a.H;
+    // The key scales live in their OWN LDS object: hipcc puts a full vmcnt(0) in front of any LDS read it cannot prove disjoint from a
+    // pending LDS-DMA destination, and a read at smem + constant + 16 hf is such a read — the softmax then waited for the V^T half
+    // requested just before it (round 4: 6.1 of an item's 23 us).  The fragment reads are at compile-time offsets and are not affected.
+    __shared__ float sk[KT * 32];              // key scales of K
+    __shared__ float sv[KT * 32];              // key scales of V
     const int wave = wave_id_uniform();
-    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
-    const int qt_raw = qb * 4 + wave;
-    const bool tile_active = qt_raw < KT;
-    const int qt = tile_active ? qt_raw : KT - 1;
-    const bool active = tile_active && qt * 32 + col < a.Lr;  // per lane: the last query tile may reach beyond the window's rows
-    EG_DBG(unsigned long long* tr = a.trace ? a.trace + 131072 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;)
-    auto mark = [&](int i) {
-        EG_DBG(if (tr && threadIdx.x == 0) {
-            tr[i] = wall_clock64();
-            if (i == 1 || i == 2) tr[5 + i] = __builtin_readcyclecounter();  // shader cycles over the S^T phase
-        })
-        (void)i;
+    // lane, hf, col are re-derived at the top of every item from a value the compiler cannot see through: left loop-invariant, ~90
+    // registers of per-lane address arithmetic were hoisted in front of the item loop and spilled to scratch — and a scratch reload
+    // behind in-flight LDS-DMA waits for it (vmcnt is in order)
+    int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const int n_items = a.BH * NQB;
+    // consecutive items (the query blocks of one (window, head), then the next head) run at the same time on one XCD: its L2 serves the
+    // second reader of a K / V^T image
+    int item = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (item >= n_items) return;
+
+    // ---- what an item needs before its first MFMA
+    struct Front {
+        int bh, qt, tile_active;
+        float sq, skr, svr;
+        int touch, touch2;
     };
-    mark(0);
+    auto locate = [&](int it, Front& f) {
+        f.bh = it / NQB;
+        const int qt_raw = (it - f.bh * NQB) * 4 + wave;
+        f.tile_active = qt_raw < KT;
+        f.qt = f.tile_active ? qt_raw : KT - 1;
+    };
     // (resources based at THIS (window, head)'s image, so that the 32-bit offsets — slice stride + a few hundred KiB — stay far below
     // the 2^31 - 1 bytes a buffer resource can span whatever the batch)
-    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.k8 + (((size_t)bh * KT * 8) << 10)), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.v8 + (((size_t)bh * 8 * KT) << 10)), 0, 0x7fffffff, 0x00020000);
-    constexpr int NPIECE = KT * 8 / 4;  // 1-KiB pieces of a half image (both slices) per wave: KT*4 blocks x 2 slices / 4 waves
+    auto k_rsrc = [&](int bh) { return __builtin_amdgcn_make_buffer_rsrc((void*)(a.k8 + (((size_t)bh * KT * 8) << 10)), 0, 0x7fffffff, 0x00020000); };
+    auto v_rsrc = [&](int bh) { return __builtin_amdgcn_make_buffer_rsrc((void*)(a.v8 + (((size_t)bh * 8 * KT) << 10)), 0, 0x7fffffff, 0x00020000); };
     // K image [kt][8 d blocks]: half `hh` = d blocks 4hh .. 4hh+3 of every key tile -> buffer layout [kt][4]
-    auto dma_k_half = [&](int hh, int buf) {
-#pragma unroll
-        for (int n = 0; n < NPIECE; ++n) {
-            const int pc = n * 4 + wave;
-            const int s = pc / (KT * 4), blk = pc - s * KT * 4, kt = blk >> 2, i = blk & 3;
-            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((kt * 8 + 4 * hh + i) << 10);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(kr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + s * HALF + (blk << 10)), 16,
-                                                     lane * 16, src, 0, 0);
-        }
+    auto dma_k_piece = [&](__amdgpu_buffer_rsrc_t kr, int hh, int buf, int n) {
+        const int pc = n * 4 + wave;
+        const int sl = pc / (KT * 4), blk = pc - sl * KT * 4, kt = blk >> 2, i = blk & 3;
+        const unsigned src = (unsigned)(sl * a.plane) + (unsigned)((kt * 8 + 4 * hh + i) << 10);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(kr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + sl * HALF + (blk << 10)), 16, lane * 16,
+                                                 src, 0, 0);
     };
     // V^T image [8 d_v tiles][kt]: half `hh` = d_v tiles 4hh .. 4hh+3 -> contiguous
-    auto dma_v_half = [&](int hh, int buf) {
-#pragma unroll
-        for (int n = 0; n < NPIECE; ++n) {
-            const int pc = n * 4 + wave;
-            const int s = pc / (KT * 4), blk = pc - s * KT * 4;
-            const unsigned src = (unsigned)(s * a.plane) + (unsigned)((4 * hh * KT + blk) << 10);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + s * HALF + (blk << 10)), 16,
-                                                     lane * 16, src, 0, 0);
-        }
-    };
-    auto dma_v_piece = [&](int hh, int buf, int n) {
+    auto dma_v_piece = [&](__amdgpu_buffer_rsrc_t vr, int hh, int buf, int n) {
         const int pc = n * 4 + wave;
         const int sl = pc / (KT * 4), blk = pc - sl * KT * 4;
         const unsigned src = (unsigned)(sl * a.plane) + (unsigned)((4 * hh * KT + blk) << 10);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + sl * HALF + (blk << 10)), 16,
-                                                 lane * 16, src, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, (__attribute__((address_space(3))) void*)(kv + buf * BUF + sl * HALF + (blk << 10)), 16, lane * 16,
+                                                 src, 0, 0);
     };
-    dma_k_half(0, 0);
-    for (int i = threadIdx.x; i < KT * 32; i += 256) {
-        sk[i] = a.sk[(size_t)bh * a.Lp + i];
-        sv[i] = a.sv[(size_t)bh * a.Lp + i];
-    }
     i32x4 qs1[8], qs2[8];
+    auto load_q = [&](const Front& f) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int8_t* p = a.q8 + ((((size_t)bh * KT + qt) * 8 + i) << 10) + lane * 16;
-        qs1[i] = *(const i32x4*)p;
-        qs2[i] = *(const i32x4*)(p + a.plane);
-    }
-    const float sq = a.sq[(size_t)bh * a.Lp + qt * 32 + col];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    mark(1);
-    dma_k_half(1, 1);
+        for (int i = 0; i < 8; ++i) {
+            const int8_t* p = a.q8 + ((((size_t)f.bh * KT + f.qt) * 8 + i) << 10) + lane * 16;
+            qs1[i] = *(const i32x4*)p;
+            qs2[i] = *(const i32x4*)(p + a.plane);
+        }
+    };
+    // the item's scales into three registers, and one dword of every 128-byte line of its Q fragments (8 KiB per slice and wave) so
+    // that the fragment loads at the item's start find them in L2 (64 registers of fragments across the PV phase do not fit)
+    auto load_scales = [&](Front& f) {
+        f.sq = a.sq[(size_t)f.bh * a.Lp + f.qt * 32 + col];
+        const int ks = min((int)threadIdx.x, KT * 32 - 1);
+        f.skr = a.sk[(size_t)f.bh * a.Lp + ks];
+        f.svr = a.sv[(size_t)f.bh * a.Lp + ks];
+        const int8_t* q = a.q8 + ((((size_t)f.bh * KT + f.qt) * 8) << 10) + lane * 128;
+        f.touch = *(const int*)q;  // (no arithmetic on them before the next item's top: a use is a wait behind the V^T DMA)
+        f.touch2 = *(const int*)(q + a.plane);
+    };
 
-    // ---- S^T = K Q^T over the two d_k halves, softmax over keys (TM:76-82), P * s_v quantised per query
-    i32x4 ps1[KT], ps2[KT], ps3[KT];  // three slices (attn_layer_i8.h quant_p): small probabilities keep their relative precision
-    float oscale;
+    Front cur;
+    locate(item, cur);
     {
-        I8Acc s[KT];
+        const __amdgpu_buffer_rsrc_t kr = k_rsrc(cur.bh);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) acc_zero(s[kt]);
-        // One unit = one d_k block x a PAIR of key tiles: 4 fragment reads, 6 MFMAs (the second MFMA into an `m` accumulator four
-        // MFMAs behind the first).  The fragments of unit u + 2 are requested before unit u's MFMAs (a ring of three): with one wave
-        // per SIMD nothing else covers the LDS latency, and hipcc left to itself sinks every read to its use (round 4 trace: 6.4 us
-        // for 2.6 us of MFMAs).  Integer accumulation: any order gives the same bits.
-        constexpr int NU = (KT + 1) / 2, NS = 4 * NU;
-        i32x4 f[3][4];
-        auto load_unit = [&](const char* img, int u, i32x4(&d)[4]) {
-            const int i = u / NU, kt0 = 2 * (u % NU);
-            const char* src = img + ((kt0 * 4 + i) << 10) + lane * 16;
-            d[0] = lds_frag(src);
-            d[1] = lds_frag(src + HALF);
-            if (kt0 + 1 < KT) {
-                d[2] = lds_frag(src + 4096);
-                d[3] = lds_frag(src + 4096 + HALF);
-            }
+        for (int n = 0; n < NPIECE; ++n) dma_k_piece(kr, 0, 0, n);
+        load_scales(cur);
+#pragma unroll
+        for (int n = 0; n < NPIECE; ++n) dma_k_piece(kr, 1, 1, n);
+    }
+
+    for (;;) {
+        asm volatile("" : "+v"(lane));
+        hf = lane >> 5;
+        col = lane & 31;
+        const int next = item + (int)gridDim.x;
+        const bool has_next = next < n_items;  // workgroup-uniform
+        const int bh = cur.bh, qt = cur.qt;
+        const int b = bh / a.H, h = bh - b * a.H;
+        const bool active = cur.tile_active && qt * 32 + col < a.Lr;  // per lane: the last query tile may reach beyond the window's rows
+        const float sq = cur.sq;
+        const __amdgpu_buffer_rsrc_t vr = v_rsrc(bh);
+        EG_DBG(unsigned long long* tr = a.trace ? a.trace + 131072 + (size_t)item * 8 : nullptr;)
+        auto mark = [&](int i) {
+            EG_DBG(if (tr && threadIdx.x == 0) {
+                tr[i] = wall_clock64();
+                if (i == 1 || i == 2) tr[5 + i] = __builtin_readcyclecounter();  // shader cycles over the S^T phase
+            })
+            (void)i;
         };
+        mark(0);
+        // both K halves and the scales of this item have been on their way since the previous item's PV phase (or the prologue above),
+        // the Q fragments' lines are in L2; the previous item's stores are in the same counter
+        load_q(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (cur.touch == 0x7fffffff && cur.touch2 == 0x7ffffffe) __builtin_amdgcn_s_sleep(1);  // (keeps the touching loads alive)
+        if (threadIdx.x < KT * 32) {
+            sk[threadIdx.x] = cur.skr;
+            sv[threadIdx.x] = cur.svr;
+        }
+        __syncthreads();
+        mark(1);
+
+        // ---- S^T = K Q^T over the two d_k halves, softmax over keys (TM:76-82), P * s_v quantised per query
+        i32x4 ps1[KT], ps2[KT], ps3[KT];  // three slices (attn_layer_i8.h quant_p): small probabilities keep their relative precision
+        float oscale;
+        Front nxt = cur;
+        {
+            I8Acc s[KT];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const char* img = kv + hh * BUF;
-            load_unit(img, 0, f[0]);
-            if (NS > 1) load_unit(img, 1, f[1]);
-#pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                if (u + 2 < NS) load_unit(img, u + 2, f[(u + 2) % 3]);
-                // second d_k half: the first V^T half streams into the buffer the barrier below freed, one piece per unit
-                if (hh == 1 && u < NPIECE) dma_v_piece(0, 0, u);
+            for (int kt = 0; kt < KT; ++kt) acc_zero(s[kt]);
+            // One unit = one d_k block x a PAIR of key tiles: 4 fragment reads, 6 MFMAs (the second MFMA into an `m` accumulator four
+            // MFMAs behind the first).  The fragments of unit u + 2 are requested before unit u's MFMAs (a ring of three): with one wave
+            // per SIMD nothing else covers the LDS latency, and hipcc left to itself sinks every read to its use.  Integer
+            // accumulation: any order gives the same bits.
+            constexpr int NU = (KT + 1) / 2, NS = 4 * NU;
+            i32x4 f[3][4];
+            auto load_unit = [&](const char* img, int u, i32x4(&d)[4]) {
                 const int i = u / NU, kt0 = 2 * (u % NU);
-                const bool two = kt0 + 1 < KT;
-                const i32x4 q1 = qs1[4 * hh + i], q2 = qs2[4 * hh + i];
-                i32x4(&c)[4] = f[u % 3];
-                s[kt0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[1], q1, s[kt0].m, 0, 0, 0);
-                if (two) s[kt0 + 1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[3], q1, s[kt0 + 1].m, 0, 0, 0);
-                s[kt0].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], q1, s[kt0].h, 0, 0, 0);
-                if (two) s[kt0 + 1].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], q1, s[kt0 + 1].h, 0, 0, 0);
-                s[kt0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], q2, s[kt0].m, 0, 0, 0);
-                if (two) s[kt0 + 1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], q2, s[kt0 + 1].m, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the buffer every wave has finished with takes the next V half; the second K half must have landed
-            if (hh == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (hh == 1) dma_v_half(1, 1);
-        }
-        mark(2);
-        float p[KT][16];
-        float mx = -INFINITY;
-        const float sq256 = sq * 256.0f * 1.44269504088896f;  // logits in units of log2(e): softmax through v_exp_f32
+                const char* src = img + ((kt0 * 4 + i) << 10) + lane * 16;
+                d[0] = lds_frag(src);
+                d[1] = lds_frag(src + HALF);
+                if (kt0 + 1 < KT) {
+                    d[2] = lds_frag(src + 4096);
+                    d[3] = lds_frag(src + 4096 + HALF);
+                }
+            };
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+            for (int hh = 0; hh < 2; ++hh) {
+                const char* img = kv + hh * BUF;
+                load_unit(img, 0, f[0]);
+                if (NS > 1) load_unit(img, 1, f[1]);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float4 k4 = *(const float4*)(sk + kt * 32 + 8 * gq + 4 * hf);
-                const float ks[4] = {k4.x, k4.y, k4.z, k4.w};
+                for (int u = 0; u < NS; ++u) {
+                    if (u + 2 < NS) load_unit(img, u + 2, f[(u + 2) % 3]);
+                    // second d_k half: the first V^T half streams into the buffer the barrier below freed, one piece per unit
+                    if (hh == 1 && u < NPIECE) dma_v_piece(vr, 0, 0, u);
+                    const int i = u / NU, kt0 = 2 * (u % NU);
+                    const bool two = kt0 + 1 < KT;
+                    const i32x4 q1 = qs1[4 * hh + i], q2 = qs2[4 * hh + i];
+                    i32x4(&c)[4] = f[u % 3];
+                    s[kt0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[1], q1, s[kt0].m, 0, 0, 0);
+                    if (two) s[kt0 + 1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[3], q1, s[kt0 + 1].m, 0, 0, 0);
+                    s[kt0].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], q1, s[kt0].h, 0, 0, 0);
+                    if (two) s[kt0 + 1].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], q1, s[kt0 + 1].h, 0, 0, 0);
+                    s[kt0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], q2, s[kt0].m, 0, 0, 0);
+                    if (two) s[kt0 + 1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], q2, s[kt0 + 1].m, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // every wave has finished with this buffer (its fragment reads were waited for by the MFMAs that used them): buffer 0
+                // takes the first V^T half (during the second d_k half), buffer 1 the second.  A RAW s_barrier: __syncthreads() carries a
+                // fence that drains vmcnt, i.e. waits for the V^T pieces already under way (gemm.h mainloop has the same note)
+                __builtin_amdgcn_s_barrier();
+                if (hh == 1) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int r = 4 * gq + c;
-                    float val = (float)i8_combine(s[kt].h[r], s[kt].m[r]) * (sq256 * ks[c]);
-                    if (kt * 32 + 8 * gq + 4 * hf + c >= a.L) val = -INFINITY;
-                    p[kt][r] = val;
-                    mx = fmaxf(mx, val);
+                    for (int n = 0; n < NPIECE; ++n) dma_v_piece(vr, 1, 1, n);
                 }
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f, pmax = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float4 v4 = *(const float4*)(sv + kt * 32 + 8 * gq + 4 * hf);
-                const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int r = 4 * gq + c;
-                    const float e = __builtin_amdgcn_exp2f(p[kt][r] - mx);
-                    sum += e;
-                    p[kt][r] = e * vs[c];  // the key's V scale rides on the probability
-                    pmax = fmaxf(pmax, p[kt][r]);
-                }
+            mark(2);
+            // the next item's scales and the lines of its Q fragments start their trip now
+            if (has_next) {
+                locate(next, nxt);
+                load_scales(nxt);
             }
-        sum += __shfl_xor(sum, 32);
-        pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
-        // q = rint(p * pk) <= P_QMAX for every p <= pmax: the quarter unit of slack covers the rounding of pk and of the product
-        const float pk = pmax > 0.f ? (P_QMAX - 0.25f) / pmax : 0.f;
-        oscale = (1.0f / sum) * (pmax / (P_QMAX - 0.25f)) * 256.0f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            u32x4 s1, s2, s3;
-            quant_p(p[kt], pk, s1, s2, s3);
-            ps1[kt] = __builtin_bit_cast(i32x4, s1);
-            ps2[kt] = __builtin_bit_cast(i32x4, s2);
-            ps3[kt] = __builtin_bit_cast(i32x4, s3);
-        }
-    }
-
-    mark(3);
-    // ---- O^T = V^T P (TM:83-88) per d_v half, heads merged on store
-    const int m = b * a.Lr + qt * 32 + col;
-    float t8[8][16];  // int8 output: the values wait for the row maximum over the head's 256 features
-    float amax = 0.f;
-    // both V^T halves were requested before the softmax: one wait, one barrier, then 4 groups (d_v half x tile pair) x KT key blocks
-    // of 4 fragment reads + 8 MFMAs, the reads two units ahead like above
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-        constexpr int NPV = 4 * KT;
-        i32x4 f[3][4];
-        auto load_unit = [&](int u, i32x4(&d)[4]) {
-            const int g = u / KT, kb = u - g * KT, dvh = g >> 1, dp = g & 1;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const char* src = kv + dvh * BUF + (((2 * dp + dt) * KT + kb) << 10) + lane * 16;
-                d[2 * dt] = lds_frag(src);
-                d[2 * dt + 1] = lds_frag(src + HALF);
-            }
-        };
-        load_unit(0, f[0]);
-        load_unit(1, f[1]);
-        PVAcc o[2];
-#pragma unroll
-        for (int u = 0; u < NPV; ++u) {
-            const int g = u / KT, kb = u - g * KT;
-            if (kb == 0) {
-                acc_zero(o[0]);
-                acc_zero(o[1]);
-            }
-            if (u + 2 < NPV) load_unit(u + 2, f[(u + 2) % 3]);
-            i32x4(&c)[4] = f[u % 3];
-            o[0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[1], ps1[kb], o[0].m, 0, 0, 0);
-            o[1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[3], ps1[kb], o[1].m, 0, 0, 0);
-            o[0].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps1[kb], o[0].h, 0, 0, 0);
-            o[1].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps1[kb], o[1].h, 0, 0, 0);
-            o[0].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps3[kb], o[0].l, 0, 0, 0);
-            o[1].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps3[kb], o[1].l, 0, 0, 0);
-            o[0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps2[kb], o[0].m, 0, 0, 0);
-            o[1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps2[kb], o[1].m, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (kb == KT - 1) {
-                if (a.o8) {
+            float p[KT][16];
+            float mx = -INFINITY;
+            const float sq256 = sq * 256.0f * 1.44269504088896f;  // logits in units of log2(e): softmax through v_exp_f32
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = pv_value(o[dt].h[r], o[dt].m[r], o[dt].l[r]) * oscale;
-                            t8[2 * g + dt][r] = v;
-                            amax = fmaxf(amax, fabsf(v));
-                        }
-                } else if (active) {
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 k4 = *(const float4*)(sk + kt * 32 + 8 * gq + 4 * hf);
+                    const float ks[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int tile = 2 * g + dt;
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            float t[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) t[e] = pv_value(o[dt].h[8 * jj + e], o[dt].m[8 * jj + e], o[dt].l[8 * jj + e]) * oscale;
-                            u32x4 hi, lo;
-                            split8(t, hi, lo);
-                            const size_t idx = acc_slot(m, h * 256 + tile * 32, jj, hf, a.HD16);
-                            *(u32x4*)(a.o + idx) = hi;
-                            *(u32x4*)(a.o + a.o_plane + idx) = lo;
-                        }
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = 4 * gq + c;
+                        float val = (float)i8_combine(s[kt].h[r], s[kt].m[r]) * (sq256 * ks[c]);
+                        if (kt * 32 + 8 * gq + 4 * hf + c >= a.L) val = -INFINITY;
+                        p[kt][r] = val;
+                        mx = fmaxf(mx, val);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f, pmax = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 v4 = *(const float4*)(sv + kt * 32 + 8 * gq + 4 * hf);
+                    const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = 4 * gq + c;
+                        const float e = __builtin_amdgcn_exp2f(p[kt][r] - mx);
+                        sum += e;
+                        p[kt][r] = e * vs[c];  // the key's V scale rides on the probability
+                        pmax = fmaxf(pmax, p[kt][r]);
+                    }
+                }
+            sum += __shfl_xor(sum, 32);
+            pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
+            // q = rint(p * pk) <= P_QMAX for every p <= pmax: the quarter unit of slack covers the rounding of pk and of the product
+            const float pk = pmax > 0.f ? (P_QMAX - 0.25f) / pmax : 0.f;
+            oscale = (1.0f / sum) * (pmax / (P_QMAX - 0.25f)) * 256.0f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                u32x4 s1, s2, s3;
+                quant_p(p[kt], pk, s1, s2, s3);
+                ps1[kt] = __builtin_bit_cast(i32x4, s1);
+                ps2[kt] = __builtin_bit_cast(i32x4, s2);
+                ps3[kt] = __builtin_bit_cast(i32x4, s3);
             }
         }
-    }
-    mark(4);
-    if (a.o8 && active) {
-        amax = fmaxf(amax, __shfl_xor(amax, 32));
-        const float inv = amax > 0.f ? I8_QMAX / amax : 0.f;
-        if (hf == 0) a.o_scale[(size_t)m * a.H + h] = amax > 0.f ? amax / I8_QMAX : 0.f;
+
+        mark(3);
+        // ---- O^T = V^T P (TM:83-88), heads merged on store
+        const int m = b * a.Lr + qt * 32 + col;
+        float t8[8][16];  // int8 output: the values wait for the row maximum over the head's 256 features
+        float amax = 0.f;
+        // both V^T halves were requested before the softmax: one wait, one barrier, then 4 groups (d_v half x tile pair) x KT key blocks
+        // of 4 fragment reads + 8 MFMAs, the reads two units ahead like above
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int mo = m;  // (the split-bf16 store addresses are formed from here on, not at the item's start: see `lane` above)
+        asm volatile("" : "+v"(mo));
+        {
+            constexpr int NPV = 4 * KT;
+            const __amdgpu_buffer_rsrc_t nkr = k_rsrc(nxt.bh);
+            i32x4 f[3][4];
+            auto load_unit = [&](int u, i32x4(&d)[4]) {
+                const int g = u / KT, kb = u - g * KT, dvh = g >> 1, dp = g & 1;
 #pragma unroll
-        for (int tile = 0; tile < 8; ++tile) {
-            u32x4 s1, s2;
-            quant16(t8[tile], inv, s1, s2);
-            const size_t idx = acc_slot_i8(m, h * 256 + tile * 32, hf, a.HD16 / 2);
-            *(u32x4*)(a.o8 + idx) = s1;
-            *(u32x4*)(a.o8 + a.o8_plane + idx) = s2;
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* src = kv + dvh * BUF + (((2 * dp + dt) * KT + kb) << 10) + lane * 16;
+                    d[2 * dt] = lds_frag(src);
+                    d[2 * dt + 1] = lds_frag(src + HALF);
+                }
+            };
+            load_unit(0, f[0]);
+            load_unit(1, f[1]);
+            PVAcc o[2];
+#pragma unroll
+            for (int u = 0; u < NPV; ++u) {
+                const int g = u / KT, kb = u - g * KT;
+                if (kb == 0) {
+                    acc_zero(o[0]);
+                    acc_zero(o[1]);
+                }
+                if (u == 2 * KT) __builtin_amdgcn_s_barrier();  // the first V^T half is spent in every wave: buffer 0 takes the next item's first K half
+                if (u + 2 < NPV) load_unit(u + 2, f[(u + 2) % 3]);
+                if (u >= 2 * KT && u - 2 * KT < NPIECE && has_next) dma_k_piece(nkr, 0, 0, u - 2 * KT);
+                i32x4(&c)[4] = f[u % 3];
+                o[0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[1], ps1[kb], o[0].m, 0, 0, 0);
+                o[1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[3], ps1[kb], o[1].m, 0, 0, 0);
+                o[0].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps1[kb], o[0].h, 0, 0, 0);
+                o[1].h = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps1[kb], o[1].h, 0, 0, 0);
+                o[0].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps3[kb], o[0].l, 0, 0, 0);
+                o[1].l = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps3[kb], o[1].l, 0, 0, 0);
+                o[0].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[0], ps2[kb], o[0].m, 0, 0, 0);
+                o[1].m = __builtin_amdgcn_mfma_i32_32x32x32_i8(c[2], ps2[kb], o[1].m, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb == KT - 1) {
+                    if (O8) {
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = pv_value(o[dt].h[r], o[dt].m[r], o[dt].l[r]) * oscale;
+                                t8[2 * g + dt][r] = v;
+                                amax = fmaxf(amax, fabsf(v));
+                            }
+                        // (pins the conversion HERE: its only consumer is the `active` branch after the loop, and hipcc would sink it
+                        // there, keeping every group's raw accumulators — 384 registers — alive until then)
+                        asm volatile("" : "+v"(amax));
+                    } else if (active) {
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const int tile = 2 * g + dt;
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                float t[8];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) t[e] = pv_value(o[dt].h[8 * jj + e], o[dt].m[8 * jj + e], o[dt].l[8 * jj + e]) * oscale;
+                                u32x4 hi, lo;
+                                split8(t, hi, lo);
+                                const size_t idx = acc_slot(mo, h * 256 + tile * 32, jj, hf, a.HD16);
+                                *(u32x4*)(a.o + idx) = hi;
+                                *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the second V^T half is spent in every wave: buffer 1 takes the next item's second K half (raw barrier: the first K half stays in flight)
+            __builtin_amdgcn_s_barrier();
+            if (has_next) {
+#pragma unroll
+                for (int n = 0; n < NPIECE; ++n) dma_k_piece(nkr, 1, 1, n);
+            }
         }
+        mark(4);
+        if (O8 && active) {
+            int ml = m;
+            asm volatile("" : "+v"(ml));
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const float inv = amax > 0.f ? I8_QMAX / amax : 0.f;
+            if (hf == 0) a.o_scale[(size_t)ml * a.H + h] = amax > 0.f ? amax / I8_QMAX : 0.f;
+#pragma unroll
+            for (int tile = 0; tile < 8; ++tile) {
+                u32x4 s1, s2;
+                quant16(t8[tile], inv, s1, s2);
+                const size_t idx = acc_slot_i8(ml, h * 256 + tile * 32, hf, a.HD16 / 2);
+                *(u32x4*)(a.o8 + idx) = s1;
+                *(u32x4*)(a.o8 + a.o8_plane + idx) = s2;
+            }
+        }
+        mark(5);
+        if (!has_next) break;
+        item = next;
+        cur = nxt;
     }
-    mark(5);
 }

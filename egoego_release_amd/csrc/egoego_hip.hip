@@ -571,25 +571,32 @@ static int launch_out_tt(const OutArgs& oa, int rows, hipStream_t s) {
     return 0;
 }
 
-template <int KT>
-static int launch_attn_core8_kt(const AttnCore8Args& a, int BH, hipStream_t s) {
-    auto kern = attn_core_i8_kernel<KT>;
-    constexpr int smem = 2 * (2 * KT * 4 * 1024) + 2 * KT * 32 * 4;  // two buffers of half an image (both slices) + key scales
+template <int KT, bool O8>
+static int launch_attn_core8_kt(AttnCore8Args a, int BH, hipStream_t s) {
+    auto kern = attn_core_i8_kernel<KT, O8>;
+    constexpr int smem = 2 * (2 * KT * 4 * 1024);  // two buffers of half an image (both slices); the key scales are static LDS
     static DevOnce once;
+    static int n_cu[64];  // compute units per device: the persistent grid (one workgroup per CU)
     if (once.pending()) {
         HIP_TRY(allow_smem(kern, smem));
+        int cu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, once.dev));
+        n_cu[once.dev & 63] = cu;
         once.done();
     }
-    kern<<<dim3((KT + 3) / 4, BH), dim3(256), smem, s>>>(a);
+    const int dev = once.dev;
+    a.BH = BH;
+    const int items = BH * ((KT + 3) / 4);
+    kern<<<dim3(std::min(items, std::max(1, n_cu[dev & 63]))), dim3(256), smem, s>>>(a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 static int launch_attn_core8(const AttnCore8Args& a, int KT, int BH, hipStream_t s) {
     switch (KT) {
-        case 1: return launch_attn_core8_kt<1>(a, BH, s);
-        case 2: return launch_attn_core8_kt<2>(a, BH, s);
-        case 4: return launch_attn_core8_kt<4>(a, BH, s);
-        case 7: return launch_attn_core8_kt<7>(a, BH, s);
+        case 1: return a.o8 ? launch_attn_core8_kt<1, true>(a, BH, s) : launch_attn_core8_kt<1, false>(a, BH, s);
+        case 2: return a.o8 ? launch_attn_core8_kt<2, true>(a, BH, s) : launch_attn_core8_kt<2, false>(a, BH, s);
+        case 4: return a.o8 ? launch_attn_core8_kt<4, true>(a, BH, s) : launch_attn_core8_kt<4, false>(a, BH, s);
+        case 7: return a.o8 ? launch_attn_core8_kt<7, true>(a, BH, s) : launch_attn_core8_kt<7, false>(a, BH, s);
     }
     return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
 }
