@@ -46,19 +46,26 @@ EG_D void quant16v(const float v[16], const float inv[16], u32x4& s1, u32x4& s2)
     }
 }
 
-// 256 features (one head of Q, K or V) x 64 tokens per workgroup, four waves side by side along the features (64 each), 256
-// registers per wave: two workgroups share a CU, so one's prologue / epilogue meets the other's main loop.
-using Q8K = GemmCfg<2, 2, 4, 1, 1, 2, false, 2, 3>;
-using Q8V = GemmCfg<2, 2, 4, 1, 1, 2, true, 2, 3>;
+// 256 features (one head of Q, K or V) x 64 NWT tokens per workgroup, waves of 64 features x 64 tokens, 4 (features) x NWT (tokens):
+//   NWT = 1  four waves, two workgroups per CU (one's prologue / epilogue meets the other's main loop) — row counts that are not a
+//            multiple of 128;
+//   NWT = 2  eight waves, one workgroup per CU (the projection tiling of attn_layer_i8w.h): the 256 KB of a feature block's weights
+//            cross L2 -> LDS once per 128 tokens instead of once per 64.  Round 4: at B = 256 x T = 196 the NWT = 1 grid moves 3.2 GB
+//            per launch through that path (9.7 TB/s at 330 us) — it, not the matrix pipe (40 % busy), is what the kernel waits for.
+template <int NWT> using Q8K = GemmCfg<2, 2, 4, NWT, 1, 2, false, 2, 3>;
+template <int NWT> using Q8V = GemmCfg<2, 2, 4, NWT, 1, 2, true, 2, 3>;
 
-__global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o) {
+template <int NWT>
+__global__ __launch_bounds__(256 * NWT, NWT == 1 ? 2 : 1) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o) {
+    constexpr int BT = 64 * NWT;  // tokens per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int fblk, tblk;
     grouped_map(lid, (int)gridDim.x / a.ntb, a.ntb, fblk, tblk);
-    const int wf = wave_id_uniform();  // feature quarter of the head
+    const int wave = wave_id_uniform();
+    const int wf = wave & 3, wt = wave >> 2;  // feature quarter of the head, token half of the block
     const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
-    const int f0 = fblk * 256 + wf * 64, t0 = tblk * 64;
+    const int f0 = fblk * 256 + wf * 64, t0 = tblk * BT + wt * 64;
     const int which = fblk * 256 / o.HD, h = (fblk * 256 % o.HD) >> 8;  // 0 = Q, 1 = K, 2 = V; head
     EG_DBG(unsigned long long* tr = o.trace ? o.trace + 131072 + (size_t)blockIdx.x * 8 : nullptr;)
     auto mark = [&](int i) {
@@ -67,26 +74,28 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
     };
     mark(0);
     const GemmOperands g{(const __bf16*)a.w8, a.w_plane / 2, (const __bf16*)a.h8, a.h_plane / 2, 16, 0, 0, 0 EG_DBG(, 0, nullptr)};
-    float* red = (float*)smem;  // [4][64] cross-wave maxima; the main loop's ring is dead when it is used
-    // the block's parameters (weight row scales and biases of its 256 features, row scales of its 64 tokens) staged in LDS behind the
-    // ring: the epilogue of a four-wave workgroup is a chain of dependent loads, and an LDS read costs a tenth of an L2 round trip
-    float* const p_ws = (float*)(smem + Q8K::SMEM_BYTES);  // [256]
-    float* const p_b = p_ws + 256;                         // [256]
-    float* const p_hs = p_b + 256;                         // [64]
-    p_ws[threadIdx.x] = a.w_scale[fblk * 256 + threadIdx.x];
-    p_b[threadIdx.x] = o.bias[fblk * 256 + threadIdx.x];
-    if (threadIdx.x < 64) p_hs[threadIdx.x] = a.h_scale[t0 + threadIdx.x];
+    float* red = (float*)smem;  // [4][BT] cross-wave maxima; the main loop's ring is dead when it is used
+    // the block's parameters (weight row scales and biases of its 256 features, row scales of its tokens) staged in LDS behind the
+    // ring: the epilogue is a chain of dependent loads, and an LDS read costs a tenth of an L2 round trip
+    float* const p_ws = (float*)(smem + Q8K<NWT>::SMEM_BYTES);  // [256]
+    float* const p_b = p_ws + 256;                              // [256]
+    float* const p_hs = p_b + 256;                              // [BT]
+    if (threadIdx.x < 256) {
+        p_ws[threadIdx.x] = a.w_scale[fblk * 256 + threadIdx.x];
+        p_b[threadIdx.x] = o.bias[fblk * 256 + threadIdx.x];
+    }
+    if (threadIdx.x < BT) p_hs[threadIdx.x] = a.h_scale[tblk * BT + threadIdx.x];
     // (visible after the first barrier of the main loop)
     I8Acc q[2][2];
     f32x16 v[2][2];
     if (which < 2) {
         // ---- Q_h / K_h: lane owns a token; one scale per row; int8 image [token tile][d_k block]
-        GemmBody<Q8K, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        GemmBody<Q8K<NWT>, NoEpi>::mainloop(g, fblk, tblk, smem, q);
         mark(1);
         const float sc = which == 0 ? o.qscale : 1.0f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float sa = p_hs[j * 32 + col];
+            const float sa = p_hs[wt * 64 + j * 32 + col];
             float amax = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
                 }
             }
             amax = fmaxf(amax, __shfl_xor(amax, 32));
-            if (hf == 0) red[wf * 64 + j * 32 + col] = amax;
+            if (hf == 0) red[wf * BT + wt * 64 + j * 32 + col] = amax;
         }
         __syncthreads();
         mark(2);
@@ -116,8 +125,8 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             const int m = t0 + j * 32 + col;
             if (m >= o.Mvalid) continue;
             const int b = m / o.Lr, l = m - b * o.Lr, bh = b * o.H + h;
-            const int tokb = j * 32 + col;
-            const float rmax = fmaxf(fmaxf(red[tokb], red[64 + tokb]), fmaxf(red[128 + tokb], red[192 + tokb]));
+            const int tokb = wt * 64 + j * 32 + col;
+            const float rmax = fmaxf(fmaxf(red[tokb], red[BT + tokb]), fmaxf(red[2 * BT + tokb], red[3 * BT + tokb]));
             const float inv = rmax > 0.f ? I8_QMAX / rmax : 0.f;
             if (wf == 0 && hf == 0) dsts[(size_t)bh * o.Lp + l] = rmax > 0.f ? rmax / I8_QMAX : 0.f;
 #pragma unroll
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
         // ---- V_h: un-swapped accumulator (lane owns a feature, registers walk the tokens); one scale per KEY row
         // (maximum over the head's 256 features: two tiles in-lane, 32 lanes by shuffles, four waves through LDS);
         // stored transposed [d_v tile][key block]
-        GemmBody<Q8V, NoEpi>::mainloop(g, fblk, tblk, smem, q);
+        GemmBody<Q8V<NWT>, NoEpi>::mainloop(g, fblk, tblk, smem, q);
         mark(1);
         float tmax[2][16];
 #pragma unroll
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             const float sw = p_ws[wf * 64 + i * 32 + col], bf = p_b[wf * 64 + i * 32 + col];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                i8_dequant_rows(q[i][j], v[i][j], sw, p_hs + j * 32 + 4 * hf);
+                i8_dequant_rows(q[i][j], v[i][j], sw, p_hs + wt * 64 + j * 32 + 4 * hf);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     v[i][j][r] += bf;
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
 #pragma unroll
                 for (int s = 1; s < 32; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
                 // token of register r: 8 (r >> 2) + 4 hf + (r & 3) within tile j
-                if (col == 0) red[wf * 64 + j * 32 + mfma32_row(r, hf)] = m;
+                if (col == 0) red[wf * BT + wt * 64 + j * 32 + mfma32_row(r, hf)] = m;
             }
         __syncthreads();
         mark(2);
@@ -173,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void qkv_i8q_kernel(QkvI8Args a, Qkv8Out o)
             float inv[16], rm[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int tokb = j * 32 + mfma32_row(r, hf);
-                rm[r] = fmaxf(fmaxf(red[tokb], red[64 + tokb]), fmaxf(red[128 + tokb], red[192 + tokb]));
+                const int tokb = wt * 64 + j * 32 + mfma32_row(r, hf);
+                rm[r] = fmaxf(fmaxf(red[tokb], red[BT + tokb]), fmaxf(red[2 * BT + tokb], red[3 * BT + tokb]));
                 inv[r] = rm[r] > 0.f ? I8_QMAX / rm[r] : 0.f;
             }
             float t[2][16];

@@ -755,16 +755,23 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 // outside the one-kernel form's range
                 {
                     ProfScope ps(c, EGOEGO_K_QKV, s);
-                    QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, rows / 64, 2 * HD / BLK_A_F};
+                    // 128-token blocks (eight waves, one workgroup per CU) once they fill the chip, else 64-token blocks (attn_core_i8.h); same bits
+                    const bool wide = rows % 128 == 0 && (rows / 128) * (3 * HD / BLK_A_F) >= 256;
+                    const int bt = wide ? 128 : 64;
+                    QkvI8Args qa{L.w_qkv8n, (size_t)3 * HD * N_MODEL, L.s_qkv, w.hA8, w.h_plane, w.hA_scale, rows / bt, 2 * HD / BLK_A_F};
                     Qkv8Out qo{(int8_t*)w.Q, (int8_t*)w.K, (int8_t*)w.V, w.qkv_plane, w.sq8, w.sk8, w.sv8, L.b_qkv,
                                1.0f / sqrtf((float)c->cfg.d_k), g.Lp, g.KT, H, HD, g.Mvalid, g.Lr EG_DBG(, g_trace)};
                     static DevOnce once;
                     if (once.pending()) {
-                        HIP_TRY(allow_smem(qkv_i8q_kernel, Q8K::SMEM_BYTES + 4096));
+                        HIP_TRY(allow_smem(qkv_i8q_kernel<1>, Q8K<1>::SMEM_BYTES + 4096));
+                        HIP_TRY(allow_smem(qkv_i8q_kernel<2>, Q8K<2>::SMEM_BYTES + 4096));
                         once.done();
                     }
                     c->last_kernel[EGOEGO_K_QKV] = "qkv_i8q_kernel";
-                    qkv_i8q_kernel<<<dim3((3 * HD / BLK_A_F) * (rows / 64)), dim3(256), Q8K::SMEM_BYTES + 4096, s>>>(qa, qo);
+                    if (wide)
+                        qkv_i8q_kernel<2><<<dim3((3 * HD / BLK_A_F) * (rows / 128)), dim3(512), Q8K<2>::SMEM_BYTES + 4096, s>>>(qa, qo);
+                    else
+                        qkv_i8q_kernel<1><<<dim3((3 * HD / BLK_A_F) * (rows / 64)), dim3(256), Q8K<1>::SMEM_BYTES + 4096, s>>>(qa, qo);
                     HIP_TRY(hipGetLastError());
                 }
                 {

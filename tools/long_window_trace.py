@@ -46,7 +46,7 @@ def report(title, tr, names):
 
 
 Lr = ((T + 1 + 15) // 16) * 16
-nq = 12 * ((B * Lr + 63) // 64)
+nq = 12 * ((B * Lr + 127) // 128)
 q = raw[131072:131072 + nq * 8].view(-1, 8)
 q = q[q[:, 3] > 0]
 report("qkv_i8q_kernel", q[:, :4], ("prologue + main loop", "dequantise + row maxima", "quantise + store"))
