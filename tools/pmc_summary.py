@@ -46,7 +46,7 @@ def main(paths):
         us_s = sum(dur[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(dur[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) if dur[k].get("SQ_VALU_MFMA_BUSY_CYCLES") else None
         clock = mean["GRBM_GUI_ACTIVE"] / N_XCD / us_g / 1e3 if us_g else None
         busy = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (us_s * 1e3 * clock) if (us_s and clock and "SQ_VALU_MFMA_BUSY_CYCLES" in mean) else None
-        print(k + "," + ",".join(f"{mean[c]:.4g}" if c in mean else "" for c in counters) + f",{n}," +
+        print(('"' + k + '"' if "," in k else k) + "," + ",".join(f"{mean[c]:.4g}" if c in mean else "" for c in counters) + f",{n}," +
               ",".join("" if v is None else f"{v:.4g}" for v in (us_g, us_s, clock, busy)))
 
 
