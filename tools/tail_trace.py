@@ -46,14 +46,17 @@ for i in range(1, 7):
     mhz = ((tr[:, 16 + i] - tr[:, 16 + prev]) / d).mean()
     print(f"{names[i]:18s} mean {d.mean():7.2f} us   min {d.min():7.2f}   max {d.max():7.2f}   shader clock {mhz:6.0f} MHz")
     prev = i
-for nm, (pro, st, en) in {"fc": (0, 7, 1), "FFN-1": (2, 8, 3), "FFN-2": (4, 9, 5)}.items():
+# (fc in the 256-register build runs its two feature halves as two passes and BOTH stamp mark 7: "fc prologue" below is the whole first
+#  pass + the second pass's pipeline fill, "chunk loop" the second pass alone — read as a 15-us prologue in round 4 until a build with
+#  the two passes as one pipeline showed a 2.6-us fill and the same 27 us of fc)
+for nm, (pro, st, en) in {"fc (pass 1 + fill of pass 2 | pass 2)": (0, 7, 1), "FFN-1": (2, 8, 3), "FFN-2": (4, 9, 5)}.items():
     print(f"{nm:6s} prologue (first chunk + weights + residual in flight -> landed) {((tr[:, st] - tr[:, pro]) / 100.0).mean():6.2f} us,"
           f" chunk loop {((tr[:, en] - tr[:, st]) / 100.0).mean():6.2f} us at {((tr[:, 16 + en] - tr[:, 16 + st]) / ((tr[:, en] - tr[:, st]) / 100.0)).mean():5.0f} MHz")
 start = (tr[:, 0] - t0) / 100.0
 early = start < 5.0  # the workgroups resident from the launch on; the others start as these finish
 for nm, sel in (("first round (start < 5 us)", early), ("later rounds", ~early)):
     if sel.any():
-        print(f"{nm:28s} n={int(sel.sum()):4d}  fc prologue {((tr[sel, 7] - tr[sel, 0]) / 100.0).mean():6.2f} us  fc loop {((tr[sel, 1] - tr[sel, 7]) / 100.0).mean():6.2f}"
+        print(f"{nm:28s} n={int(sel.sum()):4d}  fc pass 1 + fill {((tr[sel, 7] - tr[sel, 0]) / 100.0).mean():6.2f} us  fc pass 2 {((tr[sel, 1] - tr[sel, 7]) / 100.0).mean():6.2f}"
               f"  LN-1 {((tr[sel, 2] - tr[sel, 1]) / 100.0).mean():5.2f}  FFN-1 {((tr[sel, 4] - tr[sel, 2]) / 100.0).mean():5.2f}  FFN-2+LN-2 {((tr[sel, 6] - tr[sel, 4]) / 100.0).mean():5.2f}"
               f"  total {((tr[sel, 6] - tr[sel, 0]) / 100.0).mean():6.2f}")
 tot = (tr[:, 6] - tr[:, 0]) / 100.0
