@@ -210,9 +210,10 @@ def main():
 
     # warm-up: W untimed steps through the very path that is timed (packs the workspace, captures the step graph,
     # and runs the collective once so that RCCL's lazy communicator set-up is not in the timed region)
+    timed_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7)  # (checksums the weights once, outside the timed region — and BEFORE the
+    # warm-up: the checksum's host round trips between warm-up and timed region let the GPU's clocks fall back)
     if W:
         D.sample_sharded(D.hip_steps_fn(model, S - 1, W, seed=7), xs, cm, noise, force_collective=force_coll)
-    timed_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7)  # (checksums the weights once, outside the timed region)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
