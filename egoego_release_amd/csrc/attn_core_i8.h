@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
             sum += __shfl_xor(sum, 32);
             pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
             // q = rint(p * pk) <= P_QMAX for every p <= pmax: the quarter unit of slack covers the rounding of pk and of the product
-            const float pk = pmax > 0.f ? (P_QMAX - 0.25f) / pmax : 0.f;
+            const float pk = pmax > 1e-30f ? (P_QMAX - 0.25f) / pmax : 0.f;  // (below: every V row of the window is zero to fp32 — O is 0)
             oscale = (1.0f / sum) * (pmax / (P_QMAX - 0.25f)) * 256.0f;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
