@@ -59,6 +59,7 @@ class PrecisionProbe:
         if probe is None:
             B, T = self.B, model.seq_len
             xT = torch.randn((B, T, D), generator=g).to(dev)
+            self.xT = xT
             self.xc = torch.randn((B, T, D), generator=g).to(dev)
             self.x0 = xT.clone()
             ts = sorted({int(round(v)) for v in np.linspace(0, S - 1, min(10, S))}, reverse=True)
@@ -69,6 +70,9 @@ class PrecisionProbe:
             B, T = self.x0.shape[0], self.x0.shape[1]
         self.Bp, self.T = B, T
         self.eps = torch.randn((B, T, D), generator=g).to(dev)
+        if probe is not None:
+            self.xT = torch.randn((B, T, D), generator=g).to(dev)
+        self._want_chain = None
         if S > 2 and probe is None:
             self.cases.append((S // 2, self._renoise(S // 2)))
         self.n_tail = min(tail, S)
@@ -114,6 +118,25 @@ class PrecisionProbe:
                 err = max(err, float((self._x0(raw, x, t) - w0).abs().max()), float((raw - wraw).abs().max()) / wmax)
             err = max(err, float((self._tail_chain(eng) - tail).abs().max()))
             return err, eng.outlier_stats(self.Bp, self.T)
+        finally:
+            eng.close()
+
+    def _full_chain(self, eng):
+        x = self.xT.clone()
+        eng.sample_loop_(x, self.xc, self.S - 1, self.S, noise_mode=_lib.NOISE_PHILOX, seed=self.SEED + 1)
+        return x
+
+    @torch.no_grad()
+    def chain_error(self, sd, prec, row_shift=None):
+        """max-abs distance of the final poses of the WHOLE S-step ancestral chain from noise (shared Philox draws) between (sd, prec)
+        and the split-bf16 engine, on the probe batch.  What `error`'s 50-step tail under-predicts on a trained denoiser: round 4
+        measured 1.5e-4 there and 5.1e-4 here for the same packing (the high-noise half of the chain contributes as much as the end).
+        ~0.3 s per engine at S = 1000."""
+        if self._want_chain is None:
+            self._want_chain = self._full_chain(self.ref)
+        eng = HipEngine(self.cfg, sd, self.dev, prec, _lib.FLAG_NO_GRAPH, row_shift=row_shift)
+        try:
+            return float((self._full_chain(eng) - self._want_chain).abs().max())
         finally:
             eng.close()
 
