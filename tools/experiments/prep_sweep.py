@@ -1,4 +1,6 @@
-"""Whole-chain probe value of the prepared precision 9 on the trained-like checkpoint for other calibration sizes / GPTQ dampings (round 4:\n4.6e-4 ... 7.6e-4 with no trend: the whole-chain figure of one packing is a noisy statistic, tuning the preparation does not move it).\n    python tools/experiments/prep_sweep.py   (GPU)"""
+"""Whole-chain probe value of the prepared precision 9 on the trained-like checkpoint for other calibration sizes / GPTQ dampings (round 4:
+4.6e-4 ... 7.6e-4 with no trend: the whole-chain figure of one packing is a noisy statistic, tuning the preparation does not move it).
+    python tools/experiments/prep_sweep.py   (GPU)"""
 import os, sys, time, warnings, functools, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))  # run from the repo root
 warnings.simplefilter("ignore")
