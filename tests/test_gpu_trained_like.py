@@ -78,6 +78,18 @@ def test_trained_like_forward_and_chain_against_oracle(trained):
             models["auto"].hip_engine()
     auto_prec = models["auto"].hip_precision_used
     print("auto picked precision", auto_prec, "probe:", models["auto"].hip_precision_probe, "gain spread", info["gain_spread"])
+    # the pick was confirmed on the WHOLE chain (stage 2 of the probe), and every int8 candidate tried before it failed one of the stages
+    pe = models["auto"].hip_precision_probe["errors"]
+    if auto_prec != _lib.PREC_BF16X3:
+        form = f"{auto_prec} {'prepared' if models['auto'].hip_precision_probe['prepared'] else 'as is'}"
+        assert pe[form] <= models["auto"].PROBE_LIMIT and pe[form + ", full chain"] <= models["auto"].CHAIN_LIMIT, pe
+        for k, v in pe.items():
+            if k.startswith(form):
+                continue
+            if k.endswith(", full chain"):
+                assert v > models["auto"].CHAIN_LIMIT, (k, pe)
+            elif k + ", full chain" not in pe:
+                assert v > models["auto"].PROBE_LIMIT, (k, pe)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for p in (_lib.PREC_BF16X3, _lib.PREC_I8X3, _lib.PREC_I8X3_FC):
