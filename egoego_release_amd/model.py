@@ -341,7 +341,7 @@ class CondGaussianDiffusion(nn.Module):
         forwards) and takes the first one within PROBE_LIMIT of
             9 as is  ->  9 prepared  ->  8 as is  ->  8 prepared  ->  3 (with a RuntimeWarning),
         "prepared" = the pack-time transformations of precision.py (mean-shifted LayerNorm rows folded into biases, error-compensating
-        rounding of the int8 weights on the library's own grid: same kernels, same speed; ~6 s more packing per candidate (measured on the GPU box), paid only when the plain
+        rounding of the int8 weights on the library's own grid: same kernels, same speed; ~3 s more packing per candidate (measured on the GPU box), paid only when the plain
         packing fails the probe; `hip_int8_prep` = "always" / "never" forces it on / off).  An explicit int8 precision is kept (prepared
         if that is what passes) and warned about when neither form is within the limit.  The outcome is in `hip_precision_used` /
         `hip_precision_probe`."""
