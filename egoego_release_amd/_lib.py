@@ -11,6 +11,7 @@ PERFDEBUG_LIB_PATH = os.path.join(os.path.dirname(_PKG), "tools", "_build", "lib
 
 ABI_VERSION = 4
 FLAG_NO_GRAPH = 1
+FLAG_FC24 = 2  # precision 9 only: fc's weights as three int8 slices (include/egoego_hip.h)
 PRED_NOISE, PRED_X0 = 0, 1
 NOISE_INJECTED, NOISE_PHILOX, NOISE_NONE = 0, 1, 2
 PREC_BF16X3, PREC_BF16X1, PREC_I8X3, PREC_I8X3_FC = 3, 1, 8, 9

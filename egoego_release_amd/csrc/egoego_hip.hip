@@ -54,6 +54,7 @@ struct LayerDev {
     int8_t *w_1_8, *w_2_8;             // i8x3 copies of the FFN weights: two slices of [512][512], K in acc32 order
     float *s_1, *s_2;                  // their row scales [512]
     int8_t* w_fc_8;                    // i8x3 copy of w_fc: two slices of [512][HD]
+    int8_t* w_fc_3;                    // EGOEGO_FLAG_FC24: [third slice | zeros] of w_fc, or nullptr
     float* s_fc;                       // its row scales [512]
     float *b_qkv, *b_fc, *ln1_g, *ln1_b, *b_1, *b_2, *ln2_g, *ln2_b;
 };
@@ -834,6 +835,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     ta.fc8 = 1; ta.H = H;
                     ta.o8 = w.O8; ta.o8_plane = w.o_plane; ta.o_scale = w.O_scale;
                     ta.wfc8 = L.w_fc_8; ta.wfc8_plane = (size_t)N_MODEL * HD; ta.s_wfc = L.s_fc;
+                    ta.wfc8_3 = L.w_fc_3;
                 }
                 if (ffn8) {  // FFN on int8 slices: LayerNorm-1 also emits int8 rows, FFN-1 writes int8 rows
                     ta.ffn8 = 1;
@@ -1073,7 +1075,9 @@ int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
     if (cfg->precision != EGOEGO_PREC_BF16X3 && cfg->precision != EGOEGO_PREC_BF16X1 && cfg->precision != EGOEGO_PREC_I8X3 &&
         cfg->precision != EGOEGO_PREC_I8X3_FC)
         return fail(EGOEGO_E_INVALID, "unknown precision %d", cfg->precision);
-    if (cfg->flags & ~EGOEGO_FLAG_NO_GRAPH) return fail(EGOEGO_E_INVALID, "unknown flags 0x%x", cfg->flags);
+    if (cfg->flags & ~(EGOEGO_FLAG_NO_GRAPH | EGOEGO_FLAG_FC24)) return fail(EGOEGO_E_INVALID, "unknown flags 0x%x", cfg->flags);
+    if ((cfg->flags & EGOEGO_FLAG_FC24) && cfg->precision != EGOEGO_PREC_I8X3_FC)
+        return fail(EGOEGO_E_INVALID, "EGOEGO_FLAG_FC24 needs precision %d", EGOEGO_PREC_I8X3_FC);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(EGOEGO_E_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -1212,6 +1216,11 @@ int egoego_load_weights(egoego_ctx* c, const egoego_weights* wt, void* stream) {
         if ((r = dev_alloc(c, (void**)&L.w_fc_8, (size_t)2 * N_MODEL * HD, false, s))) return r;
         if ((r = dev_alloc(c, (void**)&L.s_fc, sizeof(float) * N_MODEL, false, s))) return r;
         k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_fc, HD, HD, L.w_fc_8, (size_t)N_MODEL * HD, L.s_fc, 0);
+        L.w_fc_3 = nullptr;
+        if (c->cfg.flags & EGOEGO_FLAG_FC24) {
+            if ((r = dev_alloc(c, (void**)&L.w_fc_3, (size_t)2 * N_MODEL * HD, true, s))) return r;
+            k_pack_rows_i8_third<<<N_MODEL, 256, 0, s>>>(lw.w_fc, HD, HD, L.w_fc_3, (size_t)N_MODEL * HD, 0);
+        }
         k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_1, N_MODEL, N_MODEL, L.w_1_8, (size_t)N_MODEL * N_MODEL, L.s_1, 0);
         k_pack_rows_i8<<<N_MODEL, 256, 0, s>>>(lw.w_2, N_MODEL, N_MODEL, L.w_2_8, (size_t)N_MODEL * N_MODEL, L.s_2, 0);
         HIP_TRY(hipGetLastError());

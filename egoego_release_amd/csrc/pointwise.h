@@ -52,6 +52,33 @@ __global__ __launch_bounds__(256) void k_pack_rows_i8(const float* __restrict__ 
     }
 }
 
+// The THIRD slice of a weight row on the grid of k_pack_rows_i8 (EGOEGO_FLAG_FC24) — w ~ scale * (q16 + w3 / 256), w3 = rint(256 * (w / scale - q16)),
+// stored like a first slice at dst, with an all-zero plane behind it (the "second slice" of the pass that contracts it).
+__global__ __launch_bounds__(256) void k_pack_rows_i8_third(const float* __restrict__ src, int K, int ld, int8_t* dst, size_t plane, int r0) {
+    __shared__ float red[256];
+    const int r = blockIdx.x + r0;
+    const float* row = src + (size_t)blockIdx.x * ld;
+    float mx = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(row[k]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    mx = red[0];
+    const float inv = mx > 0.f ? I8_QMAX / mx : 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float v = row[k] * inv;
+        const int q = (int)rintf(v);
+        int w3 = (int)rintf((v - (float)q) * 256.0f);
+        w3 = w3 > 127 ? 127 : (w3 < -127 ? -127 : w3);
+        const size_t idx = tiled_index_i8(r, acc32(k), K >> 5);
+        dst[idx] = (int8_t)w3;
+        dst[plane + idx] = 0;
+    }
+}
+
 // Concatenate x and x_cond (M:232) into the embed GEMM's operand: window b occupies rows
 // b*Lp .. b*Lp+Lp-1; row 0 is the (input-less) time-token slot, rows 1..T the frames, the rest
 // padding.  Columns [0, D) = x, [DP, DP + D) = x_cond, everything else zero.  The WHOLE buffer is

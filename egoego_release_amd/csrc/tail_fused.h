@@ -70,6 +70,7 @@ struct TailArgs {
     const int8_t* wfc8;      // [512][HD] two slices, wfc8_plane BYTES apart
     size_t wfc8_plane;
     const float* s_wfc;      // [512]
+    const int8_t* wfc8_3;    // EGOEGO_FLAG_FC24: [third slice | zeros] of w_fc, wfc8_plane BYTES apart, or nullptr
     // i8x3 FFN (ffn8 != 0): w_1 / w_2 as int8 slices with one scale per output row; LayerNorm-1 also emits int8 rows (ln1.q8),
     // FFN-1 writes the ReLU output as int8 rows (relu8) and FFN-2 reads them
     int ffn8;
@@ -455,6 +456,30 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
                                 acc_zero(q[i][j]);
                             }
                     }, [&] { if (fp == 0) stage_params(); });
+        }
+        // EGOEGO_FLAG_FC24: a second contraction per feature pass with the weights' THIRD slice (w ~ scale (q16 + w3 / 256)): the same
+        // chain with [w3 | 0] as the weight slices gives 256 sum(w3 a1) + sum(w3 a2), worth 1 / 65536 of the first pass's units.
+        // (Round 4: on the trained-like checkpoint fc on the 16-bit weight grid is what separates precision 9 from 8 at the end of a
+        // whole chain — 7.0e-4 against 4.3e-4 with this pass, 3.1e-4 in precision 8.  The all-zero second slice costs a third of the
+        // pass's MFMAs for nothing: the first thing to remove if this form becomes the common one.)
+        if (a.wfc8_3) {
+#pragma unroll
+            for (int fp = 0; fp < FP; ++fp) {
+                I8Acc q[FTP][TT];
+                GF::run(q, (const __bf16*)a.o8, a.o8_plane / 2, a.HD16 / 2, (const __bf16*)a.wfc8_3, a.wfc8_plane / 2, act, tt0, wave, lane, [&] {},
+                        wave * FT + fp * FTP, [&](int h) {
+                            float so[TT];
+#pragma unroll
+                            for (int j = 0; j < TT; ++j) so[j] = a.o_scale[(size_t)(tok0 + j * 32 + col) * a.H + h] * (1.0f / 256.0f);
+#pragma unroll
+                            for (int i = 0; i < FTP; ++i)
+#pragma unroll
+                                for (int j = 0; j < TT; ++j) {
+                                    i8_fold(q[i][j], acc[fp * FTP + i][j], so[j]);
+                                    acc_zero(q[i][j]);
+                                }
+                        });
+            }
         }
 #pragma unroll
         for (int i = 0; i < FT; ++i)

@@ -217,6 +217,7 @@ class CondGaussianDiffusion(nn.Module):
         self.hip_precision_probe = None   # what the pack-time probe measured: {"errors": {9: .., 8: ..}, "limit": .., "row_max": [..]}
         self.hip_probe_at_pack = True     # False: skip the probe (auto = 9, absolute envelope for the runtime guard)
         self.hip_probe_full_chain = True  # False: 'auto' trusts stage 1 of the probe (saves ~0.6 s per pack at 1000 steps)
+        self.hip_fc24 = True              # 'auto' may run precision 9 with fc's weights as three int8 slices (FLAG_FC24, ~+10 % per step) before falling back to 8
         self.hip_int8_prep = "auto"       # pack-time preparation of int8 precisions (precision.py): "auto" = only when the plain packing fails the probe; "always"; "never"
         self.hip_outlier_guard = True     # False: no read-back (and no stream sync) at the end of a chain
         self.hip_outlier_seen = None      # per LayerNorm site, the largest row maximum of the last guarded chain
@@ -240,7 +241,7 @@ class CondGaussianDiffusion(nn.Module):
         `_weights_fingerprint()` at chain-level entry points and by the `invalidate_engine()` hooks."""
         dev = self.betas.device
         return (str(dev), self.hip_precision, bool(self.hip_graph), self.objective, int(self.betas.shape[0]),
-                self.hip_int8_prep, bool(self.hip_probe_at_pack), bool(self.hip_probe_full_chain),
+                self.hip_int8_prep, bool(self.hip_probe_at_pack), bool(self.hip_probe_full_chain), bool(self.hip_fc24),
                 tuple((p.data_ptr(), p._version) for p in self._packed_tensors()))
 
     @torch.no_grad()
@@ -310,20 +311,20 @@ class CondGaussianDiffusion(nn.Module):
             self._slot.plan = plan = self._resolve_precision()
             self.hip_precision_used = plan["precision"]
             self._slot.engine = HipEngine(_engine_cfg(self), plan["sd"] if plan["sd"] is not None else self.state_dict(), dev, plan["precision"],
-                                          0 if self.hip_graph else _lib.FLAG_NO_GRAPH, row_shift=plan["row_shift"])
+                                          (0 if self.hip_graph else _lib.FLAG_NO_GRAPH) | plan.get("flags", 0), row_shift=plan["row_shift"])
             self._slot.key = key
             self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
         if masked and self._slot.plan["row_shift"]:
             if self._slot.engine_masked is None:
                 self._slot.engine_masked = HipEngine(_engine_cfg(self), self._slot.plan["sd_unshifted"], dev, self._slot.plan["precision"],
-                                                     0 if self.hip_graph else _lib.FLAG_NO_GRAPH)
+                                                     (0 if self.hip_graph else _lib.FLAG_NO_GRAPH) | self._slot.plan.get("flags", 0))
             return self._slot.engine_masked
         return self._slot.engine
 
     PROBE_LIMIT = 5e-4       # stage 1 (cheap, every candidate): largest difference from split-bf16 on the end of a chain + two forwards:
                              # half the 1e-3 bar — a short chain on other data ran 1.5-1.7x its probe figure (trained-like checkpoint)
     PROBE_TAIL = 50          # ancestral steps of stage 1's end-of-chain run
-    CHAIN_LIMIT = 6e-4       # stage 2 ("auto", the candidate that passed stage 1): the WHOLE num_timesteps chain from noise on the probe batch
+    CHAIN_LIMIT = 5.5e-4     # stage 2 ("auto", the candidate that passed stage 1): the WHOLE num_timesteps chain from noise on the probe batch
                              # (the largest of 4 windows) against split-bf16 (itself ~1e-4 from fp32 at the end of 1000 steps).  A trained
                              # denoiser's full chain ran 3.5-4.7x its stage-1 figure (1.5e-4 -> 5.1e-4 / 7.0e-4 for two draws, round 4), and
                              # the error is heavy-tailed over windows: against the fp32 oracle, 8 windows of the trained-like checkpoint ended
@@ -347,7 +348,7 @@ class CondGaussianDiffusion(nn.Module):
         `hip_precision_probe`."""
         want = self.hip_precision
         self._slot.envelope = None
-        plain = {"precision": want, "sd": None, "row_shift": None, "sd_unshifted": None, "prepared": False}
+        plain = {"precision": want, "sd": None, "row_shift": None, "sd_unshifted": None, "prepared": False, "flags": 0, "form": "as is"}
         if want != "auto" and want not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
             self.hip_precision_probe = None
             return plain
@@ -357,31 +358,38 @@ class CondGaussianDiffusion(nn.Module):
             self.hip_precision_probe = None
             return dict(plain, precision=_lib.PREC_I8X3_FC if want == "auto" else want)
         cands = (_lib.PREC_I8X3_FC, _lib.PREC_I8X3) if want == "auto" else (want,)
-        forms = {"auto": (False, True), "always": (True,), "never": (False,)}[self.hip_int8_prep]
+        # (prepared?, flags): as is, prepared, and — precision 9 under "auto" only — prepared with fc's weights as three int8 slices
+        forms = {"auto": ((False, 0), (True, 0)), "always": ((True, 0),), "never": ((False, 0),)}[self.hip_int8_prep]
         probe = PrecisionProbe(self, tail=self.PROBE_TAIL)
         errors, calib, pick, best = {}, None, None, None
         try:
             sd = probe.sd
             for prec in cands:
-                for prepared in forms:
+                pforms = forms
+                if want == "auto" and prec == _lib.PREC_I8X3_FC and self.hip_int8_prep == "auto" and self.hip_fc24:
+                    pforms = forms + ((True, _lib.FLAG_FC24),)
+                for prepared, flags in pforms:
+                    fname = ("prepared" if prepared else "as is") + (" + fc24" if flags & _lib.FLAG_FC24 else "")
                     if prepared:
                         calib = probe.calibration() if calib is None else calib
-                        sd_s, row_shift = prepare_int8_state(sd, calib, prec, shift=True)
+                        fc24 = bool(flags & _lib.FLAG_FC24)
+                        sd_s, row_shift = prepare_int8_state(sd, calib, prec, shift=True, fc24=fc24)
                         # for padding-mask calls: the same rounded weights and K / V shifts, no LayerNorm-row shift (no second rounding pass)
                         sd_u, _ = prepare_int8_state({k: (sd_s[k] if k.endswith(".weight") else v) for k, v in sd.items()}, calib, prec,
-                                                     shift=False, rounding=False)
+                                                     shift=False, rounding=False, fc24=fc24)
                     else:
                         sd_s, row_shift, sd_u = sd, None, None
-                    err, row_max = probe.error(sd_s, prec, row_shift)
-                    errors[(prec, "prepared" if prepared else "as is")] = err
-                    cand = {"precision": prec, "sd": sd_s if prepared else None, "row_shift": row_shift, "sd_unshifted": sd_u, "prepared": prepared}
+                    err, row_max = probe.error(sd_s, prec, row_shift, flags)
+                    errors[(prec, fname)] = err
+                    cand = {"precision": prec, "sd": sd_s if prepared else None, "row_shift": row_shift, "sd_unshifted": sd_u, "prepared": prepared,
+                            "flags": flags, "form": fname}
                     if best is None or err < best[0]:
                         best = (err, cand, row_max)
                     if err <= self.PROBE_LIMIT:
                         if want == "auto" and self.hip_probe_full_chain:
                             # stage 2, for the candidate that would run: the WHOLE chain from noise against split-bf16
-                            cerr = probe.chain_error(sd_s, prec, row_shift)
-                            errors[(prec, ("prepared" if prepared else "as is") + ", full chain")] = cerr
+                            cerr = probe.chain_error(sd_s, prec, row_shift, flags)
+                            errors[(prec, fname + ", full chain")] = cerr
                             if cerr > self.CHAIN_LIMIT:
                                 continue
                         pick = cand
@@ -393,7 +401,8 @@ class CondGaussianDiffusion(nn.Module):
         explicit_best = want != "auto" and pick is None
         self.hip_precision_probe = {"errors": {f"{p} {f}": e for (p, f), e in errors.items()}, "limit": self.PROBE_LIMIT,
                                     "row_max": row_max if pick is not None else (best[2] if explicit_best else None),
-                                    "prepared": bool(pick["prepared"] if pick else (explicit_best and best[1]["prepared"]))}
+                                    "prepared": bool(pick["prepared"] if pick else (explicit_best and best[1]["prepared"])),
+                                    "form": (pick["form"] if pick else (best[1]["form"] if explicit_best else None))}
         if pick is not None:
             self._slot.envelope = row_max
             return pick
@@ -431,10 +440,10 @@ class CondGaussianDiffusion(nn.Module):
         probe = PrecisionProbe(self, probe=(x[:n], x_cond[:n]), tail=self.PROBE_TAIL)
         try:
             psd = plan["sd"] if plan["sd"] is not None else probe.sd
-            err, _ = probe.error(psd, prec, plan["row_shift"])
+            err, _ = probe.error(psd, prec, plan["row_shift"], plan.get("flags", 0))
             ok = err <= self.PROBE_LIMIT
             if ok and self.hip_probe_full_chain:
-                err = probe.chain_error(psd, prec, plan["row_shift"])
+                err = probe.chain_error(psd, prec, plan["row_shift"], plan.get("flags", 0))
                 ok = err <= self.CHAIN_LIMIT
         finally:
             probe.close()

@@ -104,12 +104,12 @@ class PrecisionProbe:
         return self._want
 
     @torch.no_grad()
-    def error(self, sd, prec, row_shift=None):
+    def error(self, sd, prec, row_shift=None, flags=0):
         """max over: the end of the probe's chain (final poses), and per forward the clamped x0 prediction (absolute) and the raw
         output relative to max(1, |y|max) — of (sd, prec) against the split-bf16 engine on the module's own weights.
         Returns (error, [row maxima per LayerNorm site the run recorded])."""
         fw, tail = self._reference()
-        eng = HipEngine(self.cfg, sd, self.dev, prec, _lib.FLAG_NO_GRAPH, row_shift=row_shift)
+        eng = HipEngine(self.cfg, sd, self.dev, prec, _lib.FLAG_NO_GRAPH | flags, row_shift=row_shift)
         try:
             err = 0.0
             for (tv, x), (w0, wraw, wmax) in zip(self.cases, fw):
@@ -127,14 +127,14 @@ class PrecisionProbe:
         return x
 
     @torch.no_grad()
-    def chain_error(self, sd, prec, row_shift=None):
+    def chain_error(self, sd, prec, row_shift=None, flags=0):
         """max-abs distance of the final poses of the WHOLE S-step ancestral chain from noise (shared Philox draws) between (sd, prec)
         and the split-bf16 engine, on the probe batch.  What `error`'s 50-step tail under-predicts on a trained denoiser: round 4
         measured 1.5e-4 there and 5.1e-4 here for the same packing (the high-noise half of the chain contributes as much as the end).
         ~0.3 s per engine at S = 1000."""
         if self._want_chain is None:
             self._want_chain = self._full_chain(self.ref)
-        eng = HipEngine(self.cfg, sd, self.dev, prec, _lib.FLAG_NO_GRAPH, row_shift=row_shift)
+        eng = HipEngine(self.cfg, sd, self.dev, prec, _lib.FLAG_NO_GRAPH | flags, row_shift=row_shift)
         try:
             return float((self._full_chain(eng) - self._want_chain).abs().max())
         finally:
@@ -214,7 +214,7 @@ def compensated_rounding(W, X, damp=0.01, block=128):
 
 
 @torch.no_grad()
-def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=False):
+def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=False, fc24=False):
     """The state dict an int8-slice engine of precision `prec` is packed from: mean-shifted LayerNorm rows (folded into biases and
     LayerNorm shifts), K / V minus their mean rows, and compensated rounding of the weights that precision contracts on int8
     slices.  Returns (state dict, row_shift) where row_shift = {'embed' | (layer, 'attn_ln' | 'out' | 'k' | 'v' | 'attn_out'): m} are
@@ -227,6 +227,8 @@ def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=Fals
     def get(k):  # (the latest version: several folds may touch one bias)
         return out[k].detach().to(dev, torch.float32)
     int8_w = {"qkv", "w_1", "w_2"} | ({"fc", "linear_out"} if prec == _lib.PREC_I8X3_FC else set())
+    if fc24:  # FLAG_FC24: the library takes THREE slices of fc's weights — they keep their fp32 values
+        int8_w.discard("fc")
     names = {"qkv": ("self_attn.w_q", "self_attn.w_k", "self_attn.w_v"), "fc": ("self_attn.fc",), "w_1": ("pos_ffn.w_1",), "w_2": ("pos_ffn.w_2",)}
     # ---- weights: compensated rounding on the grid the library will pack them onto
     W = {}

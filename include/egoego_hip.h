@@ -89,6 +89,11 @@ typedef struct {
 /* egoego_sample_loop / egoego_ddim_loop capture one diffusion step into a hipGraph and replay it for the rest of the
  * chain (the timestep lives in device memory); this flag launches every kernel of every step individually instead. */
 enum { EGOEGO_FLAG_NO_GRAPH = 1 };
+/* EGOEGO_PREC_I8X3_FC only: fc's weights (self_attn.fc, TM:55) as THREE int8 slices — w = scale * (q16 + w3 / 256): a second
+ * contraction per feature pass adds the third slice's products (about +10 % time per step).  On a trained checkpoint fc on the
+ * 16-bit grid is what separates precision 9 from 8 at the end of a 1000-step chain; the Python layer's "auto"
+ * tries this form before falling back to precision 8.  Hand the fc weights over UNROUNDED when it is set. */
+enum { EGOEGO_FLAG_FC24 = 2 };
 
 /* fp32 device tensors in the reference checkpoint layout, contiguous. */
 typedef struct {

@@ -81,7 +81,7 @@ def test_trained_like_forward_and_chain_against_oracle(trained):
     # the pick was confirmed on the WHOLE chain (stage 2 of the probe), and every int8 candidate tried before it failed one of the stages
     pe = models["auto"].hip_precision_probe["errors"]
     if auto_prec != _lib.PREC_BF16X3:
-        form = f"{auto_prec} {'prepared' if models['auto'].hip_precision_probe['prepared'] else 'as is'}"
+        form = f"{auto_prec} {models['auto'].hip_precision_probe['form']}"
         assert pe[form] <= models["auto"].PROBE_LIMIT and pe[form + ", full chain"] <= models["auto"].CHAIN_LIMIT, pe
         for k, v in pe.items():
             if k.startswith(form):
