@@ -111,13 +111,16 @@ EG_D i32x4 tail_load(tail_rsrc r, int voff, unsigned soff) {
 // one MFMA group that uses it; each fragment is consumed >= FT*TT MFMAs after its read was issued.
 // I8 = true: the operands are int8 slices (k-blocks of 32; "hi" plane = slice 1, "lo" plane = slice 2) and the sums go to
 // an I8Acc pair — s2*s1 and s1*s2 into .m, s1*s1 into .h, the groups in the order of the split-bf16 parts.
-template <int FT, int TT, int RING, bool LAST, int DP, int NKS = 8, bool I8 = false>
+template <int FT, int TT, int RING, bool LAST, int DP, int NKS = 8, bool I8 = false, bool WLO0 = false>
 struct TailChunk {
     using AccT = typename std::conditional<I8, I8Acc, f32x16>::type;
     static constexpr int PD = RING - 1, NW = FT * 2;  // NKS < 8: the short last chunk of a contraction whose k-blocks are no multiple of 8
+    // WLO0: the weights' second slice is all zero (the third-slice pass of EGOEGO_FLAG_FC24): it is neither loaded nor multiplied
+    static constexpr int NWL = WLO0 ? FT : NW;  // weight loads per k-step
+    static_assert(!WLO0 || I8, "int8 slices only");
     static_assert(NKS == 8 || (LAST && DP == 0), "only the last chunk may be short");
     static_assert(RING == 2 || RING == 4 || RING == 8, "ring slots must divide the 8 k-steps of a chunk");
-    static constexpr int n_ops(int s) { return ((s + PD < NKS || !LAST) ? NW : 0) + (s == 0 ? DP : 0); }
+    static constexpr int n_ops(int s) { return ((s + PD < NKS || !LAST) ? NWL : 0) + (s == 0 ? DP : 0); }
     // vector-memory operations issued after the DMA pieces: what may stay in flight when the next chunk must have landed
     static constexpr int after_dma() {
         int n = 0;
@@ -128,7 +131,7 @@ struct TailChunk {
     static constexpr int allowed(int ks) {
         int n = 0;
         if (ks < PD) {
-            n += (PD - 1 - ks) * NW;
+            n += (PD - 1 - ks) * NWL;
             for (int s = 0; s < ks; ++s) n += n_ops(s);
         } else {
             n += ks - PD == 0 ? DP : 0;
@@ -161,7 +164,7 @@ struct TailChunk {
             constexpr int kn = KS + PD;
 #pragma unroll
             for (int q = 0; q < NW; ++q)
-                if (!(TAIL_ABLATE & 1)) wq[kn % RING][q] = tail_load(wr, lane * 16, kn < 8 ? wcur[q] + (kn << 10) : wnext[q] + ((kn & 7) << 10));
+                if (!(TAIL_ABLATE & 1) && !(WLO0 && (q & 1))) wq[kn % RING][q] = tail_load(wr, lane * 16, kn < 8 ? wcur[q] + (kn << 10) : wnext[q] + ((kn & 7) << 10));
         }
         if (KS == 0 && DP) {
 #pragma unroll
@@ -177,10 +180,12 @@ struct TailChunk {
         const i32x4(&w)[NW] = wq[KS % RING];
         // part-major (two MFMAs on one accumulator are never back to back), in the order of gemm.h's mma_part:
         // lo*hi, hi*lo, hi*hi.  w[2i] = hi plane of feature tile i, w[2i+1] = lo plane.
+        if (!WLO0) {
 #pragma unroll
-        for (int i = 0; i < FT; ++i)
+            for (int i = 0; i < FT; ++i)
 #pragma unroll
-            for (int j = 0; j < TT; ++j) mma<0>(w[2 * i + 1], ah[cur][j], acc[i][j]);
+                for (int j = 0; j < TT; ++j) mma<0>(w[2 * i + 1], ah[cur][j], acc[i][j]);
+        }
         asm volatile("" ::: "memory");
         wait_counts<63, (KS < NKS - 1 ? TT : 0)>();  // the lo-plane activations of this k-step
         __builtin_amdgcn_sched_barrier(0);
@@ -233,7 +238,7 @@ struct TailChunk {
 // I8: int8-slice operands ([R/32][K/32][2][32][16] byte planes, the two slices `*_plane` bf16-element units = bytes / 2
 // apart; K16 then counts 32-wide k-blocks) accumulated into I8Acc pairs.
 // NWAVES: waves of the workgroup (4, or the 8 of the eight-wave all-int8 tail): they share the LDS-DMA pieces of a chunk.
-template <int FT, int TT, int RING, bool REM2 = false, bool I8 = false, int NWAVES = 4>
+template <int FT, int TT, int RING, bool REM2 = false, bool I8 = false, int NWAVES = 4, bool WLO0 = false>
 struct DirectGemm {
     using AccT = typename std::conditional<I8, I8Acc, f32x16>::type;
     static constexpr int NW = 2 * FT, PD = RING - 1;
@@ -285,7 +290,8 @@ struct DirectGemm {
 #pragma unroll
         for (int k = 0; k < PD; ++k)
 #pragma unroll
-            for (int q = 0; q < NW; ++q) wq[k][q] = tail_load(wr, lane * 16, wcur[q] + (k << 10));
+            for (int q = 0; q < NW; ++q)
+                if (!(WLO0 && (q & 1))) wq[k][q] = tail_load(wr, lane * 16, wcur[q] + (k << 10));
 #pragma unroll
         for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -297,7 +303,7 @@ struct DirectGemm {
         for (int q = 0; q + 1 < NQ; ++q) {
             w_offsets(8 * q, wcur);
             w_offsets(8 * q + 8, wnext);
-            TailChunk<FT, TT, RING, false, DMA_PIECES, 8, I8>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
+            TailChunk<FT, TT, RING, false, DMA_PIECES, 8, I8, WLO0>::run(acc, wq, wr, wcur, wnext, act + (q & 1) * CH_BYTES, CH_PLANE, lane,
                                                              [&](int piece) { dma_piece(q + 1, piece); });
             post(q);
             // the next chunk has landed (counted wait inside run) and everyone is done with this one
@@ -305,7 +311,7 @@ struct DirectGemm {
             asm volatile("" ::: "memory");
         }
         w_offsets(8 * (NQ - 1), wcur);
-        TailChunk<FT, TT, RING, true, 0, (REM2 ? 2 : 8), I8>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
+        TailChunk<FT, TT, RING, true, 0, (REM2 ? 2 : 8), I8, WLO0>::run(acc, wq, wr, wcur, wcur, act + ((NQ - 1) & 1) * CH_BYTES, CH_PLANE, lane, [](int) {});
         post(NQ - 1);
         __syncthreads();  // every wave is done with the chunk buffers before the next GEMM's first DMA
     }
@@ -460,13 +466,14 @@ __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_ker
         // EGOEGO_FLAG_FC24: a second contraction per feature pass with the weights' THIRD slice (w ~ scale (q16 + w3 / 256)): the same
         // chain with [w3 | 0] as the weight slices gives 256 sum(w3 a1) + sum(w3 a2), worth 1 / 65536 of the first pass's units.
         // (Round 4: on the trained-like checkpoint fc on the 16-bit weight grid is what separates precision 9 from 8 at the end of a
-        // whole chain — 7.0e-4 against 4.3e-4 with this pass, 3.1e-4 in precision 8.  The all-zero second slice costs a third of the
-        // pass's MFMAs for nothing: the first thing to remove if this form becomes the common one.)
+        // whole chain — 7.0e-4 against 4.3e-4 with this pass, 3.1e-4 in precision 8.  The all-zero second weight slice is neither loaded
+        // nor multiplied: DirectGemm's WLO0 form, two MFMAs per product.)
         if (a.wfc8_3) {
 #pragma unroll
             for (int fp = 0; fp < FP; ++fp) {
                 I8Acc q[FTP][TT];
-                GF::run(q, (const __bf16*)a.o8, a.o8_plane / 2, a.HD16 / 2, (const __bf16*)a.wfc8_3, a.wfc8_plane / 2, act, tt0, wave, lane, [&] {},
+                using GF3 = DirectGemm<FTP, TT, (NWV == 8 ? TAIL8_RING_FC : (W2 ? 4 : TAIL_RING1)), false, true, NWV, true>;  // second weight slice: zero, skipped
+                GF3::run(q, (const __bf16*)a.o8, a.o8_plane / 2, a.HD16 / 2, (const __bf16*)a.wfc8_3, a.wfc8_plane / 2, act, tt0, wave, lane, [&] {},
                         wave * FT + fp * FTP, [&](int h) {
                             float so[TT];
 #pragma unroll
