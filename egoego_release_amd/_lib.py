@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegoego_hip.so")
 PERFDEBUG_LIB_PATH = os.path.join(os.path.dirname(_PKG), "tools", "_build", "libegoego_hip_perfdebug.so")  # tools/ only: `build --perfdebug`
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_NO_GRAPH = 1
 FLAG_FC24 = 2  # precision 9 only: fc's weights as three int8 slices (include/egoego_hip.h)
 PRED_NOISE, PRED_X0 = 0, 1

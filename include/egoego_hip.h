@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define EGOEGO_ABI_VERSION 4
+#define EGOEGO_ABI_VERSION 5 /* 5: EGOEGO_FLAG_FC24 */
 
 enum {
     EGOEGO_OK = 0,
