@@ -353,6 +353,45 @@ def test_small_grid_kernels_give_the_bits_of_the_large_grid_ones():
         assert torch.equal(b, a[:n]), n
 
 
+@pytest.mark.parametrize("T", [120, 196])
+def test_fc_weights_as_three_slices(T):
+    """EGOEGO_FLAG_FC24 (precision 9): fc's weights as three int8 slices — a second contraction per feature pass with the third slice.
+    On the reference's initialisation the denoiser stays inside precision 9's error (the third slice only removes weight rounding),
+    the result differs from the two-slice engine (the pass really runs), a window has the same bits in a small call (eight-wave tail)
+    and in a large one (two 256-register workgroups per CU), and the flag is refused for any other precision."""
+    from egoego_release_amd.engine import HipEngine
+    from egoego_release_amd.precision import _engine_cfg
+    cfg, sd, m = _model(T=T, precision=_lib.PREC_I8X3_FC)
+    ecfg = _engine_cfg(m)
+    dev = torch.device("cuda")
+    e24 = HipEngine(ecfg, m.state_dict(), dev, _lib.PREC_I8X3_FC, _lib.FLAG_NO_GRAPH | _lib.FLAG_FC24)
+    e16 = HipEngine(ecfg, m.state_dict(), dev, _lib.PREC_I8X3_FC, _lib.FLAG_NO_GRAPH)
+    try:
+        g = torch.Generator().manual_seed(11)
+        B = 200
+        x = torch.randn(B, T, 198, generator=g)
+        xc = torch.randn(B, T, 198, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        with torch.no_grad():
+            want = O.denoise(sd, torch.cat((x[:2], xc[:2]), -1), t[:2])
+        big = e24.denoise(x.cuda(), xc.cuda(), t.cuda())
+        small = e24.denoise(x[:3].contiguous().cuda(), xc[:3].contiguous().cuda(), t[:3].contiguous().cuda())
+        plain = e16.denoise(x[:3].contiguous().cuda(), xc[:3].contiguous().cuda(), t[:3].contiguous().cuda())
+        assert torch.equal(small, big[:3])
+        assert not torch.equal(small, plain)
+        d24, d16 = small[:2].cpu() - want, plain[:2].cpu() - want
+        e24_err, e16_err = float(d24.abs().max()), float(d16.abs().max())
+        r24, r16 = float(d24.pow(2).mean().sqrt()), float(d16.pow(2).mean().sqrt())
+        print(f"T={T}: max error fc24 {e24_err:.2e} / two slices {e16_err:.2e}; rms {r24:.2e} / {r16:.2e}")
+        # the maxima are single elements and move either way by a third; the rms may only fall (the third slice removes rounding)
+        assert e24_err < 6e-4 and r24 < 1.03 * r16
+    finally:
+        e24.close()
+        e16.close()
+    with pytest.raises(_lib.EgoEgoHipError):
+        HipEngine(ecfg, m.state_dict(), dev, _lib.PREC_I8X3, _lib.FLAG_FC24)
+
+
 @pytest.mark.filterwarnings("ignore:LayerNorm gains span")  # (explicit int8 precisions on such a checkpoint: the module says so)
 @pytest.mark.parametrize("T", [120, 196, 48])
 def test_outlier_heavy_weights_stay_within_the_bar(prec, T):
