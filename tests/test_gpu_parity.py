@@ -491,7 +491,7 @@ def test_outlier_heavy_layernorm_gains_step_the_default_precision_down():
     pr = m.hip_precision_probe
     assert pr["errors"]["9 as is"] > pr["limit"]  # the plain int8 packing measures outside the limit on this checkpoint ...
     if m.hip_precision_used == _lib.PREC_BF16X3:  # ... so either every int8 form was measured and split-bf16 runs, with a warning,
-        assert set(pr["errors"]) == {"9 as is", "9 prepared", "8 as is", "8 prepared"}
+        assert {"9 as is", "9 prepared", "9 prepared + fc24", "8 as is", "8 prepared"} <= set(pr["errors"])  # (+ ", full chain" entries of stage 2)
         assert any("falling back to split-bf16" in str(w.message) for w in rec)
     else:                                         # ... or a PREPARED int8 packing measured inside it (precision.py)
         assert pr["prepared"] and not rec
