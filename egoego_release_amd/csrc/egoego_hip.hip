@@ -593,13 +593,9 @@ static int launch_attn_core8_kt(AttnCore8Args a, int BH, hipStream_t s) {
     return 0;
 }
 static int launch_attn_core8(const AttnCore8Args& a, int KT, int BH, hipStream_t s) {
-    switch (KT) {
-        case 1: return a.o8 ? launch_attn_core8_kt<1, true>(a, BH, s) : launch_attn_core8_kt<1, false>(a, BH, s);
-        case 2: return a.o8 ? launch_attn_core8_kt<2, true>(a, BH, s) : launch_attn_core8_kt<2, false>(a, BH, s);
-        case 4: return a.o8 ? launch_attn_core8_kt<4, true>(a, BH, s) : launch_attn_core8_kt<4, false>(a, BH, s);
-        case 7: return a.o8 ? launch_attn_core8_kt<7, true>(a, BH, s) : launch_attn_core8_kt<7, false>(a, BH, s);
-    }
-    return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
+    // (only windows of 129..224 tokens take this path: seven key tiles; shorter ones run the one-kernel layer or the split-bf16 core)
+    if (KT != 7) return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
+    return a.o8 ? launch_attn_core8_kt<7, true>(a, BH, s) : launch_attn_core8_kt<7, false>(a, BH, s);
 }
 
 // ------------------------------------------------------------------------------------ the step
