@@ -91,6 +91,54 @@ def cpu_baseline(cfg, sd, B, T, budget_s=25.0):
             "ms_per_step": 1e3 * el / n}
 
 
+def trained_like_line(args, cfg, dev, B, T, K, W):
+    """The same timed region (K graph-replayed steps after W warm-up steps, inputs resident) on a TRAINED-LIKE checkpoint — the
+    module's own training loss optimised for --train-steps Adam steps on synthetic motion, on this GPU, right here
+    (tools/make_trained_like_checkpoint.py) — in what hip_precision = "auto" picks for it by measurement: what a checkpoint that is
+    no longer the initialisation runs at (the headline `value` is the seeded initialisation)."""
+    import torch
+    from egoego_release_amd import _lib, make_head_windows
+    from egoego_release_amd import dist as D
+    from egoego_release_amd.model import CondGaussianDiffusion
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_trained_like_checkpoint import train_like
+    t_train = time.perf_counter()
+    sd, info = train_like(args.train_steps, 0, dev, T)
+    t_train = time.perf_counter() - t_train
+    sd = {k: v for k, v in sd.items() if k.startswith("denoise_fn.")}
+    model = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    model.load_state_dict(sd, strict=False)
+    model.hip_graph = not args.no_graph
+    model = model.to(dev)
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        t_pack = time.perf_counter()
+        model.hip_engine(verify=True)
+        t_pack = time.perf_counter() - t_pack
+    xs, cm = make_head_windows(B, T, seed=100)
+    gen = torch.Generator().manual_seed(1234)
+    noise = {"x_T": torch.randn(xs.shape, generator=gen).to(dev), "cond": torch.randn(xs.shape, generator=gen).to(dev)}
+    xs, cm = xs.to(dev), cm.to(dev)
+    S = cfg.timesteps
+    timed_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7, verify=False, guard=False)
+    D.sample_local(D.hip_steps_fn(model, S - 1, max(W, 1), seed=7), xs, cm, noise)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    D.sample_local(timed_fn, xs, cm, noise)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    eng = model.hip_engine()
+    probe = model.hip_precision_probe or {}
+    return {"precision": int(model.hip_precision_used), "form": probe.get("form"), "plan_source": probe.get("source"),
+            "ms_per_step": 1e3 * el / K, "steps_per_s": K / el, "steps": K, "warmup": W,
+            "probe_errors": probe.get("errors"), "probe_limits": {"stage1": probe.get("limit"), "whole_chain": probe.get("chain_limit"),
+                                                                  "chain_windows": probe.get("chain_windows")},
+            "attention_kernel": eng.last_kernel("qkv"), "tail_kernel": eng.last_kernel("fc_ln"),
+            "checkpoint": {k: info[k] for k in ("steps", "seed", "lr", "loss_first", "loss_last", "gain_spread")},
+            "train_s": t_train, "pack_s": t_pack, "warnings": [str(w.message)[:200] for w in rec]}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -133,6 +181,8 @@ def main():
                          "needs an explicit --precision")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every step (no hipGraph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trained-like", action="store_true",
+                    help="skip the extra `trained_like` object (N=1 only: the same timed region on the trained-like checkpoint, in what 'auto' picks for it)")
     ap.add_argument("--dump", default=None, help="rank 0 saves the gathered poses of the timed call here (tests)")
     args = ap.parse_args()
 
@@ -193,7 +243,7 @@ def main():
         model.hip_outlier_guard = False
     model.hip_graph = not args.no_graph
     model = model.to(dev)
-    eng = model.hip_engine(verify=True)
+    eng = model.hip_engine(verify=True, group=D._group_of(None))  # (N > 1: group rank 0 measures, every rank packs its plan)
     prec = int(model.hip_precision_used)  # what runs: the probe's pick under "auto"
 
     # the GLOBAL batch (every rank holds it: 24 MB per tensor at B=256); rank r samples the contiguous slice
@@ -210,10 +260,11 @@ def main():
 
     # warm-up: W untimed steps through the very path that is timed (packs the workspace, captures the step graph,
     # and runs the collective once so that RCCL's lazy communicator set-up is not in the timed region)
-    timed_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7)  # (checksums the weights once, outside the timed region — and BEFORE the
-    # warm-up: the checksum's host round trips between warm-up and timed region let the GPU's clocks fall back)
-    if W:
-        D.sample_sharded(D.hip_steps_fn(model, S - 1, W, seed=7), xs, cm, noise, force_collective=force_coll)
+    # the timed call neither checksums the weights nor reads the runtime guard's monitors back (host round trips): the warm-up call
+    # just before it does both (and agrees on ONE plan over the ranks, plan.py); the guard of the timed chain runs after t1
+    timed_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7, verify=False, guard=False)
+    D.sample_sharded(D.hip_steps_fn(model, S - 1, max(W, 1), seed=7), xs, cm, noise, force_collective=force_coll)
+    prec = int(model.hip_precision_used)  # (under torch.distributed: what group rank 0 resolved)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -231,6 +282,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    model._outlier_guard(*timed_fn.last, group=D._group_of(None))  # the timed chain's LayerNorm monitors (collective verdict), outside the timed region
     gather_ms, sample_ms = 1e3 * (t2 - t1), 1e3 * (t1 - t0)
     if dist:
         tmax = torch.tensor([el, gather_ms, sample_ms], device=dev, dtype=torch.float64)
@@ -376,6 +428,11 @@ def main():
             "roofline": dominant,
             "roofline_second_kernel": other,
         }
+        if world == 1 and not args.no_trained_like and args.weights == "synthetic" and args.precision == "auto":
+            try:
+                out_json["trained_like"] = trained_like_line(args, cfg, dev, B, T, K, W)
+            except Exception as e:  # the headline stands on its own
+                out_json["trained_like"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out_json["cpu_baseline"] = cpu_baseline(cfg, sd, B, T)

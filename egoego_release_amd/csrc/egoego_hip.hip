@@ -973,15 +973,18 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             if (int r = act8_only ? launch_out_tt<1, true>(oa, rows, s) : launch_out_tt<1, false>(oa, rows, s)) return r;
         } else if (NP == 2 && act8_only) {
             // the last layer's output exists as int8 rows only: linear_out on int8 slices, 256 features x 128 tokens per eight-wave workgroup
-            GemmOperands go{(const __bf16*)c->w_out_8, (size_t)c->NOUT * N_MODEL / 2, (const __bf16*)w.hA8, w.h_plane / 2, N_MODEL / 32, 1, rows / 128, row0 / 128 EG_DBG(, 0, nullptr)};
+            GemmOperands go{(const __bf16*)c->w_out_8, (size_t)c->NOUT * N_MODEL / 2, (const __bf16*)w.hA8, w.h_plane / 2, N_MODEL / 32, 1, rows / 128, row0 / 128 EG_DBG(, g_ablate, g_trace)};
             auto kern = gemm_i8_kernel<AW8K, EpiOut<2>>;
+            // (after the main loop the ring's LDS holds the block's x rows: EpiOut::run_block)
+            const int out_smem = std::max((int)AW8K::SMEM_BYTES, AW8K::BT * c->cfg.d_feats * 4 + 16);
             static DevOnce once;
             if (once.pending()) {
-                HIP_TRY(allow_smem(kern, AW8K::SMEM_BYTES));
+                HIP_TRY(allow_smem(kern, 160 * 1024));
                 once.done();
             }
+            if (out_smem > 160 * 1024) return fail(EGOEGO_E_INVALID, "d_feats too large for the linear_out kernel's LDS staging");
             c->last_kernel[EGOEGO_K_OUT] = "gemm_i8_kernel:EpiOut";
-            kern<<<dim3(go.ntb), dim3(AW8K::NT), AW8K::SMEM_BYTES, s>>>(go, c->s_out, w.hA_scale, EpiOut<2>{io.out});
+            kern<<<dim3(go.ntb), dim3(AW8K::NT), out_smem, s>>>(go, c->s_out, w.hA_scale, EpiOut<2>{io.out});
             HIP_TRY(hipGetLastError());
         } else {
             GemmOperands go{c->w_out, (size_t)c->NOUT * N_MODEL, w.hA, w.h_plane, N_MODEL / 16, 1, tb_c, t0_c EG_DBG(, g_ablate, g_trace)};

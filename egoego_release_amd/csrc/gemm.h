@@ -142,6 +142,10 @@ EG_D void mma_part(int part, I8One& c, bf16x8 wh, bf16x8 wl, bf16x8 ah, bf16x8 a
 template <class AccT, int NP> struct AccParts { static constexpr int N = NP == 2 ? 3 : 1; };
 template <int NP> struct AccParts<I8One, NP> { static constexpr int N = NP == 2 ? 2 : 1; };
 
+// Epilogues that offer run_block (EpiOut: the workgroup's x rows staged through LDS) declare BLOCK_ROWS
+template <class E, class = void> struct epi_block_rows : std::false_type {};
+template <class E> struct epi_block_rows<E, std::enable_if_t<E::BLOCK_ROWS>> : std::true_type {};
+
 template <class C, class Epi>
 struct GemmBody {
     // main loop only: on return acc[ft][tt] holds the pre-epilogue sums of this wave's tile.
@@ -377,7 +381,7 @@ struct GemmBody {
 
     static __device__ void run(const GemmOperands& g, const Epi& epi, int fblk, int tblk, char* smem) {
         f32x16 acc[C::FT][C::TT];
-        mainloop(g, fblk, tblk, smem, acc);
+        [[clang::always_inline]] mainloop(g, fblk, tblk, smem, acc);
         const int wave = wave_id_uniform();
         const int lane = threadIdx.x & 63;
         const int wf = wave % C::NWF, wt = wave / C::NWF;
@@ -387,7 +391,11 @@ struct GemmBody {
             if (acc[0][0][0] == 123.456f) *(float*)smem = acc[C::FT - 1][C::TT - 1][7];  // keep the MFMAs alive
             return;
         })
-        epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
+        if constexpr (epi_block_rows<Epi>::value && C::WT * 32 >= 256 && C::SMEM_BYTES >= C::BT * 1024 + 16) {
+            epi.template run_block<C::FT, C::TT, C::BT, C::NT>(acc, f0, t0, tblk * C::BT, lane, smem);  // (the workgroup owns every output feature of its rows)
+        } else {
+            epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
+        }
         EG_DBG(if (g.trace) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (threadIdx.x == 0) g.trace[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_kernel(GemmOperands g, Ep
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int fblk, tblk;
     grouped_map(lid, g.nfb, g.ntb, fblk, tblk);
-    GemmBody<C, Epi>::run(g, epi, fblk, tblk + g.tblk0, smem);
+    [[clang::always_inline]] GemmBody<C, Epi>::run(g, epi, fblk, tblk + g.tblk0, smem);
 }
 
 // Q/K feature blocks run swapped, V feature blocks un-swapped; the branch is block-uniform.
@@ -489,10 +497,18 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_i8_kernel(GemmOperands g,
     f32x16 acc[C::FT][C::TT];
     {
         I8Acc q[C::FT][C::TT];
-        GemmBody<C, Epi>::mainloop(g, fblk, tblk, smem, q);
+        [[clang::always_inline]] GemmBody<C, Epi>::mainloop(g, fblk, tblk, smem, q);  // (with run_block's copy loops inlined below, hipcc would otherwise call it)
         i8_dequant_tile<true>(q, acc, sw, sa, f0, t0, lane);
     }
-    epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
+    if constexpr (epi_block_rows<Epi>::value && C::WT * 32 >= 256) {  // (the workgroup owns every output feature of its rows)
+        epi.template run_block<C::FT, C::TT, C::BT, C::NT>(acc, f0, t0, tblk * C::BT, lane, smem);
+    } else {
+        epi.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
+    }
+    EG_DBG(if (g.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) g.trace[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
+    })
 }
 
 // un-swapped accumulator (lane owns a feature, registers walk tokens)
@@ -1171,12 +1187,24 @@ struct OutDyn {
     float a_prev, dir, sig;  // DDIM coefficients of this step
 };
 
+// Explicit address spaces for EpiOut::run_block: hipcc does not infer LDS through its offsets, and x comes out of the step state
+// (a pointer loaded from memory is generic to it).  Native vectors: HIP's float2 / float4 classes cannot carry an address space.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) f32x2 LdsF2;
+typedef __attribute__((address_space(3))) f32x4 LdsF4;
+typedef __attribute__((address_space(1))) f32x2 GlbF2;
+typedef __attribute__((address_space(1))) f32x4 GlbF4;
 template <int NP>
 struct EpiOut {
     OutParams p;
-    // one group = 4 consecutive features f..f+3 of one frame
-    __device__ void group(const float (&o)[4], int f, int m, int b, int frame, size_t row, int t, float c1, float c2,
-                          float sigma, float srec, float srecm1, float abar, const OutDyn& d) const {
+    // Kernels whose workgroup owns ALL the (padded) output features of its token rows may stage the x rows through LDS (run_block)
+    static constexpr bool BLOCK_ROWS = true;
+    // one group = 4 consecutive features f..f+3 of one frame.  xs (run_block): this frame's row of x in LDS — read x_t from it and
+    // leave the new x there instead of in global memory (same values either way)
+    template <bool STAGED>
+    EG_D void group(const float (&o)[4], int f, int m, int b, int frame, size_t row, int t, float c1, float c2,
+                          float sigma, float srec, float srecm1, float abar, const OutDyn& d, float* xs) const {
         if (p.mode == 0) {
 #pragma unroll
             for (int c = 0; c < 4; c += 2)
@@ -1187,9 +1215,15 @@ struct EpiOut {
 #pragma unroll
         for (int c = 0; c < 4; c += 2)
             if (f + c < p.D) {
-                const float2 v = *(const float2*)(d.x + row + f + c);
-                xt[c] = v.x;
-                xt[c + 1] = v.y;
+                if (STAGED) {
+                    const f32x2 v = *(const LdsF2*)(xs + f + c);
+                    xt[c] = v.x;
+                    xt[c + 1] = v.y;
+                } else {
+                    const float2 v = *(const float2*)(d.x + row + f + c);
+                    xt[c] = v.x;
+                    xt[c + 1] = v.y;
+                }
             }
         if (sigma != 0.f) {  // the step's noise scale: ancestral sigma_t (mode 1) or the DDIM sig (mode 2, eta > 0)
             if (p.noise_mode == 0) {
@@ -1226,7 +1260,10 @@ struct EpiOut {
         }
 #pragma unroll
         for (int c = 0; c < 4; c += 2)
-            if (f + c < p.D) *(float2*)(d.x + row + f + c) = make_float2(xn[c], xn[c + 1]);
+            if (f + c < p.D) {
+                if (STAGED) *(LdsF2*)(xs + f + c) = f32x2{xn[c], xn[c + 1]};
+                else *(float2*)(d.x + row + f + c) = make_float2(xn[c], xn[c + 1]);
+            }
         uint2 hi, lo;
         split4(xn, hi, lo);
         const size_t idx = tiled_index(m, f, p.KE16);
@@ -1234,11 +1271,11 @@ struct EpiOut {
         if (NP == 2) *(uint2*)(p.xall + p.xall_plane + idx) = lo;
     }
 
-    template <int FT, int TT>
-    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
-        const int hf = lane >> 5, col = lane & 31;
+    // what this launch reads from the step state (or from OutParams for a single step)
+    EG_D OutDyn dynamic(int& step, int& t_loop) const {
         OutDyn d{p.x, p.noise, p.prefix, p.seed, p.window_offset, 1.0f, 0.f, 0.f};
-        int step = 0, t_loop = 0;
+        step = 0;
+        t_loop = 0;
         if (p.state) {
             step = p.state->out_step - 1;
             t_loop = p.ts ? p.ts[step] : p.state->t_start - step;
@@ -1254,6 +1291,13 @@ struct EpiOut {
             const float4 dd = *(const float4*)(p.ddim_tab + 4 * step);
             d.a_prev = dd.x; d.dir = dd.y; d.sig = dd.z;
         }
+        return d;
+    }
+
+    // xs0: LDS copy of the x rows [r_first, ...) of the workgroup's tokens (run_block) or nullptr (x read and written in place)
+    template <int FT, int TT, bool STAGED>
+    EG_D void tiles(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, const OutDyn& d, int t_loop, float* xs0, int r_first) const {
+        const int hf = lane >> 5, col = lane & 31;
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
             const int m = t0 + j * 32 + col;
@@ -1261,6 +1305,7 @@ struct EpiOut {
             const bool valid = (b < p.B) && (lw >= 1) && (lw <= p.T);
             const int frame = lw - 1;
             const size_t row = valid ? ((size_t)b * p.T + frame) * p.D : 0;
+            float* xs = STAGED ? xs0 + (valid ? (b * p.T + frame - r_first) * p.D : 0) : nullptr;
             float c1 = 0.f, c2 = 0.f, sigma = 0.f, srec = 0.f, srecm1 = 0.f, abar = 0.f;
             int t = 0;
             if (valid && p.mode != 0) {
@@ -1277,9 +1322,54 @@ struct EpiOut {
                         const float4 b4 = *(const float4*)(p.bias + f);
                         const float o[4] = {acc[i][j][4 * g + 0] + b4.x, acc[i][j][4 * g + 1] + b4.y,
                                             acc[i][j][4 * g + 2] + b4.z, acc[i][j][4 * g + 3] + b4.w};
-                        group(o, f, m, b, frame, row, t, c1, c2, sigma, srec, srecm1, abar, d);
+                        group<STAGED>(o, f, m, b, frame, row, t, c1, c2, sigma, srec, srecm1, abar, d, xs);
                     }
                 }
         }
+    }
+
+    template <int FT, int TT>
+    __device__ void run(f32x16 (&acc)[FT][TT], int f0, int t0, int lane, int, int, char*) const {
+        int step, t_loop;
+        const OutDyn d = dynamic(step, t_loop);
+        tiles<FT, TT, false>(acc, f0, t0, lane, d, t_loop, nullptr, 0);
+    }
+
+    // The same for a workgroup of NT threads that owns all DP features of the BT token rows from blk_t0 on (after its main loop's
+    // closing barrier; `smem` holds BT * D floats + 16 bytes).  A lane owns a token, so `run` reads and writes x 8 bytes at a time
+    // in 32 different rows per instruction; but the x rows of a block's valid tokens are ONE contiguous range of the [B][T][D]
+    // tensor (the padding rows between two windows have no x, and a window's last frame is followed by the next one's first):
+    // it is copied into LDS 16 bytes per lane, updated there, and copied back.  Same values as `run`.
+    template <int FT, int TT, int BT, int NT>
+    EG_D void run_block(f32x16 (&acc)[FT][TT], int f0, int t0, int blk_t0, int lane, char* smem) const {
+        int step, t_loop;
+        const OutDyn d = dynamic(step, t_loop);
+#ifndef EGOEGO_OUT_DIRECT
+#define EGOEGO_OUT_DIRECT 0  // (A/B knob of variant builds: 1 = x read and written in place by every kernel, round 4's form)
+#endif
+        if (EGOEGO_OUT_DIRECT || p.mode == 0 || (p.D & 1)) {  // (raw model output: nothing to read; an odd row length: rows are not 8-byte aligned)
+            tiles<FT, TT, false>(acc, f0, t0, lane, d, t_loop, nullptr, 0);
+            return;
+        }
+        // first and last valid frame of the block, as rows of the [B * T][D] tensor
+        const int m1 = blk_t0 + BT - 1;
+        const int b0 = blk_t0 / p.Lp, lw0 = blk_t0 % p.Lp, b1 = m1 / p.Lp, lw1 = m1 % p.Lp;
+        const int r_first = lw0 > p.T ? (b0 + 1) * p.T : b0 * p.T + max(lw0 - 1, 0);
+        const int r_last = min(lw1 == 0 ? b1 * p.T - 1 : b1 * p.T + min(lw1, p.T) - 1, p.B * p.T - 1);
+        const int n = max(r_last - r_first + 1, 0) * p.D;  // floats (even)
+        float* const gx = d.x + (size_t)r_first * p.D;
+        const int mis = (int)(((size_t)r_first * p.D) & 3);  // 0 or 2: LDS index = global index + mis, so 16-byte pieces line up on both sides
+        float* const xs0 = (float*)smem + mis;
+        const int head = min((4 - mis) & 3, n), body = (n - head) >> 2, tail = n - head - 4 * body;
+        __syncthreads();  // (every wave is done with the operand buffers this overlays)
+        if ((int)threadIdx.x < head / 2) *(LdsF2*)(xs0 + 2 * threadIdx.x) = *(const GlbF2*)(gx + 2 * threadIdx.x);
+        for (int i = threadIdx.x; i < body; i += NT) *(LdsF4*)(xs0 + head + 4 * i) = *(const GlbF4*)(gx + head + 4 * i);
+        if ((int)threadIdx.x < tail / 2) *(LdsF2*)(xs0 + head + 4 * body + 2 * threadIdx.x) = *(const GlbF2*)(gx + head + 4 * body + 2 * threadIdx.x);
+        __syncthreads();
+        tiles<FT, TT, true>(acc, f0, t0, lane, d, t_loop, xs0, r_first);
+        __syncthreads();
+        if ((int)threadIdx.x < head / 2) *(GlbF2*)(gx + 2 * threadIdx.x) = *(const LdsF2*)(xs0 + 2 * threadIdx.x);
+        for (int i = threadIdx.x; i < body; i += NT) *(GlbF4*)(gx + head + 4 * i) = *(const LdsF4*)(xs0 + head + 4 * i);
+        if ((int)threadIdx.x < tail / 2) *(GlbF2*)(gx + head + 4 * body + 2 * threadIdx.x) = *(const LdsF2*)(xs0 + head + 4 * body + 2 * threadIdx.x);
     }
 };

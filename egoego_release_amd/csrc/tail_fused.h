@@ -670,5 +670,9 @@ __global__ __launch_bounds__(256, 1) void out_kernel(OutArgs a) {
         using G = DirectGemm<FT, TT, TAIL_RING_IO>;
         G::run(acc, a.h, a.h_plane, 32, a.w, a.w_plane, smem, tb * TT, wave, lane, [] {}, (fh * 4 + wave) * FT);
     }
-    a.epi.template run<FT, TT>(acc, (fh * 4 + wave) * FT * 32, tb * 32 * TT, lane, wave, 0, smem);
+    if constexpr (FS == 1) {  // the workgroup owns whole rows: x staged through LDS (EpiOut::run_block; 32 TT rows of <= 256 floats fit the chunk buffers)
+        a.epi.template run_block<FT, TT, 32 * TT, 256>(acc, wave * FT * 32, tb * 32 * TT, tb * 32 * TT, lane, smem);
+    } else {
+        a.epi.template run<FT, TT>(acc, (fh * 4 + wave) * FT * 32, tb * 32 * TT, lane, wave, 0, smem);
+    }
 }

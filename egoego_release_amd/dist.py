@@ -17,19 +17,23 @@ def shard_bounds(n_windows, rank, world):
 
 
 def gather_windows(local, n_windows, group=None, force=False):
-    """all_gather the per-rank [b_r, T, D] slices back into [n_windows, T, D] on every rank.
+    """all_gather the per-rank [b_r, T, D] slices back into [n_windows, T, D] on every rank: ONE collective
+    (`all_gather_into_tensor`) into one preallocated [world * pad, T, D] buffer, pad = the largest shard; with even shards the
+    buffer IS the result (no copy), ragged ones are compacted once.
     force=True runs the collective even with one rank (exercises RCCL init + all_gather on a 1-GPU box)."""
     world = dist.get_world_size(group)
     if world == 1 and not force:
         return local
     sizes = [shard_bounds(n_windows, r, world) for r in range(world)]
     pad = max(1, max(hi - lo for lo, hi in sizes))
-    buf = local
-    if local.shape[0] < pad:  # uneven shards: pad to the largest so all_gather sees equal shapes
-        buf = torch.cat((local, local.new_zeros(pad - local.shape[0], *local.shape[1:])), 0)
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf.contiguous(), group=group)
-    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], 0)
+    send = local.contiguous()
+    if send.shape[0] < pad:  # ragged shards: the collective needs equal shapes
+        send = torch.cat((send, send.new_zeros(pad - send.shape[0], *send.shape[1:])), 0)
+    out = torch.empty((world * pad,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    if all(hi - lo == pad for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * pad: r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
 
 
 def sample_local(sample_fn, x_start, cond_mask, init_noise, group=None):
@@ -40,7 +44,10 @@ def sample_local(sample_fn, x_start, cond_mask, init_noise, group=None):
     sl = slice(lo, hi)
     # fewer windows than ranks: a rank with an empty slice still calls sample_fn (which returns an empty tensor on
     # ITS device and dtype) so that what it hands to the collective matches the other ranks'
-    return sample_fn(x_start[sl], cond_mask[sl], {k: v[sl] for k, v in init_noise.items()}, lo)
+    args = (x_start[sl], cond_mask[sl], {k: v[sl] for k, v in init_noise.items()}, lo)
+    if getattr(sample_fn, "wants_global", False):  # (the HIP sample functions size their plan by the GLOBAL job)
+        return sample_fn(*args, global_windows=x_start.shape[0])
+    return sample_fn(*args)
 
 
 def sample_sharded(sample_fn, x_start, cond_mask, init_noise, group=None, force_collective=False):
@@ -58,55 +65,57 @@ def sample_sharded(sample_fn, x_start, cond_mask, init_noise, group=None, force_
     return gather_windows(local, x_start.shape[0], group, force=force_collective)
 
 
-def hip_sample_fn(model, seed=0):
-    """sample_fn for `sample_sharded` that runs the HIP path with in-kernel Philox noise.
+def _group_of(group):
+    """The group whose ranks must agree on one plan: `group`, or the default group once torch.distributed is initialised."""
+    if not dist.is_initialized():
+        return None
+    return group if group is not None else dist.group.WORLD
+
+
+def hip_steps_fn(model, t_start, n_steps, seed=0, group=None, verify=True, guard=True):
+    """sample_fn for `sample_sharded`: `n_steps` ancestral steps from timestep `t_start` downwards on the HIP path with in-kernel
+    Philox noise (hip_sample_fn = the whole chain; bench.py times a slice of it).
 
     ALWAYS Philox: the per-step draws are keyed by (seed; global window index, timestep, frame, feature), which is what makes the
     result independent of the number of ranks.  The reference's torch-RNG draw order (`model.sampling_rng = "torch"`, one
     `randn_like` of the WHOLE batch per step, M:253) cannot be reproduced by a shard that only holds part of the batch; a caller
     who needs the reference's exact draws samples unsharded through `model.sample()`.
 
-    The weights are checksummed against the packed copy once, here (in-place updates made before this call are picked up); the
-    returned function then reuses the context without re-checksumming — make a new function after updating weights."""
+    ONE plan for all ranks (plan.py): every call checksums the weights (in-place updates between calls are picked up; `verify=False`
+    skips that — bench.py's timed call, whose weights were checked just before), agrees over the group on whether to re-pack, and
+    packs what group rank 0 resolved; the runtime guard's verdict at the end of the chain is collective too (`guard=False`: the
+    caller runs `model._outlier_guard(eng, x, x_cond, group)` itself, outside its timed region).  Every rank of the group must make
+    the same calls — with an empty slice too (fewer windows than ranks)."""
     from . import _lib
 
-    model.hip_engine(verify=True)
+    grp = _group_of(group)
 
-    def fn(xs, cm, noise, window_offset):
-        eng = model.hip_engine()
+    def fn(xs, cm, noise, window_offset, global_windows=None):
         dev = model.betas.device
         x = noise["x_T"].to(dev, torch.float32).contiguous().clone()
-        if x.shape[0] == 0:
-            return x
-        xs, cm = xs.to(dev), cm.to(dev)
-        x_cond = (xs * (1.0 - cm) + cm * noise["cond"].to(dev)).float().contiguous()
-        S = model.num_timesteps
-        eng.sample_loop_(x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
-        model._outlier_guard(eng, x, x_cond)
+        job = (int(global_windows if global_windows is not None else x.shape[0]), int(x.shape[1]), int(n_steps))
+        eng = model.hip_engine(verify=verify, job=job, group=grp if verify else None)
+        if x.shape[0]:
+            xs, cm = xs.to(dev), cm.to(dev)
+            x_cond = (xs * (1.0 - cm) + cm * noise["cond"].to(dev)).float().contiguous()
+            eng.sample_loop_(x, x_cond, t_start, n_steps, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
+            model._note_job((x.shape[0], x.shape[1], n_steps))
+        else:
+            x_cond = x
+        fn.last = (eng, x, x_cond)
+        if guard:
+            model._outlier_guard(eng, x, x_cond, group=grp)
         return x
 
+    fn.last = None
+    fn.wants_global = True
     return fn
 
 
-def hip_steps_fn(model, t_start, n_steps, seed=0):
-    """Like hip_sample_fn (Philox draws, weights checksummed once at creation), but `n_steps` ancestral steps from timestep
-    `t_start` downwards (a slice of the chain): what bench.py times."""
-    from . import _lib
-
-    model.hip_engine(verify=True)
-
-    def fn(xs, cm, noise, window_offset):
-        eng = model.hip_engine()
-        dev = model.betas.device
-        x = noise["x_T"].to(dev, torch.float32).contiguous().clone()
-        if x.shape[0] == 0:
-            return x
-        x_cond = (xs.to(dev) * (1.0 - cm.to(dev)) + cm.to(dev) * noise["cond"].to(dev)).float().contiguous()
-        eng.sample_loop_(x, x_cond, t_start, n_steps, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
-        model._outlier_guard(eng, x, x_cond)
-        return x
-
-    return fn
+def hip_sample_fn(model, seed=0, group=None):
+    """The whole `num_timesteps` chain (see hip_steps_fn)."""
+    S = model.num_timesteps
+    return hip_steps_fn(model, S - 1, S, seed=seed, group=group)
 
 
 # ------------------------------------------------------------------------------------------ sequence-level sharding of the harness
@@ -129,6 +138,9 @@ def harness_sharded(model, ds, head_pose, sample_bs=1, seed=0, parents=None, gro
     the windows of one pair never leave its rank (window k + 1 in-paints the tail of window k, M:395-467).  No collective in
     the loop; ONE all_gather of the stitched (axis-angle, root) result ends the call.  Draws: `harness_noise` + Philox keyed by
     the global pair index, so the result is the same for any number of ranks.
+    `seed` keys EVERY draw of the call: the initial ones (`harness_noise`) and the per-step Philox stream (the model's
+    `philox_seed` is set from it for the call), so two calls with different seeds share no noise.
+    All ranks sample from one plan and the runtime guard's verdict is collective (plan.py; a rank without pairs joins in).
     Returns (local axis-angle [Bseq * sample_bs, T', 22, 3], root [Bseq * sample_bs, T', 3]) on every rank.
     harness_fn(head_pose_slice, noise_slice, pair_offset) -> (aa, root): stand-in for tests; default = the HIP harness."""
     from . import harness
@@ -139,13 +151,21 @@ def harness_sharded(model, ds, head_pose, sample_bs=1, seed=0, parents=None, gro
     seq_len = model.seq_len
     noise = harness_noise(n, n_frames, seq_len, seed)
     lo, hi = shard_bounds(n, rank, world)
-    if harness_fn is None:
+    own = harness_fn is None
+    if own:
         dev = model.betas.device
+        grp = _group_of(group)
 
         def harness_fn(hp, nz, off):
-            return harness.full_body_gen_cond_head_pose_sliding_window(model, ds, hp.to(dev), noise=nz, parents=parents, window_offset=off)
+            keep = model.philox_seed
+            model.philox_seed = int(seed) * 1000003 + 11  # (+ the window index inside the harness)
+            try:
+                return harness.full_body_gen_cond_head_pose_sliding_window(model, ds, hp.to(dev), noise=nz, parents=parents,
+                                                                           window_offset=off, group=grp)
+            finally:
+                model.philox_seed = keep
     t_out = harness.output_frames(n_frames, seq_len)
-    if hi > lo:
+    if hi > lo or own:  # (the HIP harness of a rank without pairs still walks the group's collective calls)
         nz = {"x_all": noise["x_all"][lo:hi], "cond": [c[lo:hi] for c in noise["cond"]]}
         aa, root = harness_fn(pairs[lo:hi], nz, lo)
         local = torch.cat((aa.reshape(hi - lo, t_out, 66), root.reshape(hi - lo, t_out, 3)), dim=-1).float().contiguous()

@@ -234,21 +234,31 @@ def output_frames(num_frames, seq_len):
 
 @torch.no_grad()
 def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos, global_head_jquat, cond_mask,
-                                             noise=None, parents=None, window_offset=0):
+                                             noise=None, parents=None, window_offset=0, group=None):
     """M:329-467.  Windows of `model.seq_len` frames, stride seq_len-10; window k+1 is conditioned on the
     last 10 frames of window k, re-canonicalised, by overwriting its first 10 frames after every step.
 
     noise: {'x_all': [B,T,D], 'cond': [per-window [B,Tw,D]], 'steps': [per-window [S,B,Tw,D]]} injects every draw (tests);
     without 'steps' the per-step draws are in-kernel Philox keyed by (philox_seed + window; window_offset + b, ...), i.e. by the
     GLOBAL sequence index — what dist.harness_sharded uses so that the result does not depend on how sequences are sharded.
+    group (dist.harness_sharded): the process group whose ranks sample from one plan (model.hip_engine / _outlier_guard are
+    collective then); a rank without sequences (b = 0) walks the same collective calls and returns empty tensors.
     """
-    eng = model.hip_engine(verify=True)
-    parents = _parents_of(ds, parents)
-    device = model.betas.device
     b = shape[0]
     S = model.num_timesteps
     seq_len = model.seq_len
     stride = seq_len - OVERLAP
+    spans = window_spans(global_head_jpos.shape[1], seq_len)
+    job = (b * len(spans), seq_len, S)
+    eng = model.hip_engine(verify=True, job=job, group=group)
+    device = model.betas.device
+    if b == 0:
+        empty = torch.zeros((0, seq_len, 198), device=device)
+        for _ in spans:
+            model._outlier_guard(eng, empty, empty, group=group)
+        t_out = output_frames(global_head_jpos.shape[1], seq_len)
+        return torch.zeros((0, t_out, 22, 3), device=device), torch.zeros((0, t_out, 3), device=device)
+    parents = _parents_of(ds, parents)
     x_all = noise["x_all"].to(device).float() if noise is not None else torch.randn(shape, device=device)
     jpos_all = global_head_jpos.to(device)
     jquat_all = global_head_jquat.to(device)
@@ -286,7 +296,8 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
                              window_offset=window_offset, prefix=pfx)
         else:
             model._torch_rng_chain(eng, curr_x, x_cond, S, pfx)
-        model._outlier_guard(eng, curr_x, x_cond)  # (may re-pack in another precision: take the engine afresh for the next window)
+        model._note_job((b, curr_x.shape[1], S))
+        model._outlier_guard(eng, curr_x, x_cond, group=group)  # (may re-pack in another precision — on every rank of the group alike —: take the engine afresh for the next window)
         eng = model.hip_engine()
         aa, root, head = convert_model_res_to_data(ds, curr_x, recover, cur_jpos, parents)
         if t_idx == 0:
@@ -321,21 +332,21 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
 
 @torch.no_grad()
 def sample_sliding_window_w_canonical(model, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None,
-                                      parents=None, window_offset=0):
+                                      parents=None, window_offset=0, group=None):
     model.denoise_fn.eval()
     res = p_sample_loop_sliding_window_w_canonical(model, ds, x_start.shape, global_head_jpos, global_head_jquat,
-                                                   cond_mask, noise=noise, parents=parents, window_offset=window_offset)
+                                                   cond_mask, noise=noise, parents=parents, window_offset=window_offset, group=group)
     model.denoise_fn.train()
     return res
 
 
 @torch.no_grad()
-def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None, parents=None, window_offset=0):
+def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None, parents=None, window_offset=0, group=None):
     """head_pose [B,T,7] = xyz + quaternion (w,x,y,z) -> (local axis-angle [B,T',22,3], root [B,T',3])."""
     jpos, jquat = head_pose[:, :, :3], head_pose[:, :, 3:]
     data = torch.zeros(head_pose.shape[0], head_pose.shape[1], 198, device=head_pose.device)
     return sample_sliding_window_w_canonical(model, ds, jpos, jquat, data, prep_head_condition_mask(data), noise=noise,
-                                             parents=parents, window_offset=window_offset)
+                                             parents=parents, window_offset=window_offset, group=group)
 
 
 # ------------------------------------------------------------------------------------------ checkpoints

@@ -23,7 +23,8 @@ from torch import nn
 
 from . import _lib
 from .engine import HipEngine
-from .precision import PrecisionProbe, prepare_int8_state, _engine_cfg
+from . import plan as plan_mod
+from .precision import PrecisionProbe, _engine_cfg
 from .synthetic import sinusoid_position_table
 
 
@@ -137,6 +138,11 @@ def _linear_betas(timesteps):
     return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
 
 
+def _world(group):
+    import torch.distributed as tdist
+    return tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
+
+
 def _extract(a, t, x_shape):
     return a.gather(-1, t).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
 
@@ -153,6 +159,7 @@ class _EngineSlot:
         self.envelope = None   # per LayerNorm site: the largest row maximum the pack-time probe has validated (runtime guard)
         self.demoted = False   # the runtime guard measured the int8 precision outside the limit on live inputs: "auto" now means 3
         self.force_repack = False  # ... and asked for the re-pack that applies it (a re-pack for any other reason clears `demoted`)
+        self.unprobed_work = 0     # window-steps sampled on a "small job" context (split-bf16, no probe): plan.is_small_job
 
     def __deepcopy__(self, memo):
         return _EngineSlot()
@@ -197,28 +204,28 @@ class CondGaussianDiffusion(nn.Module):
             ("p2_loss_weight", (p2_loss_weight_k + abar / (1 - abar)) ** -p2_loss_weight_gamma),
         ):
             self.register_buffer(name, val.to(torch.float32))
-        # MI355X-specific knobs (not in the reference): operand precision and the noise source.
-        # PREC_I8X3_FC (9, the fastest mode inside the 1e-3 bar at every batch size): every attention front end, fc, the FFN and
-        # linear_out on int8 slices with int8-only activations between the kernels of a step — the one-kernel attention layer for
-        # windows of 64 < T+1 <= 128 tokens, int8 projections + int8 core for longer ones (<= 224), int8 projections +
-        # split-bf16 core and split-bf16 fc for shorter ones; embed split-bf16.  ~3e-4 from the fp32 reference on one forward and
-        # on the full chain.  PREC_I8X3 (8): fc, linear_out and the residuals stay split-bf16, ~1.3e-4, ~40 % more time per step;
-        # PREC_BF16X3 (3): split-bf16 everywhere, ~2.5e-5, ~80-90 % more.
-        # A checkpoint with LayerNorm gains far above the rest costs the int8 modes precision (one scale per row = 16-bit fixed
-        # point; measured limits in DESIGN.md 3c, tools/hostile_weights_check.py, tools/precision_compare.py).
-        # "auto" (default): decided by MEASUREMENT whenever the weights are (re)packed (`_resolve_precision`): the int8 precisions'
-        # x0 predictions on a fixed probe batch are compared with split-bf16's on the same device, and 9, else 8, is taken only if it
-        # stays within PROBE_LIMIT; `hip_precision_used` / `hip_precision_probe` tell what was picked and what was measured.  While an
-        # int8 precision runs, the LayerNorm epilogues record their largest row maxima (egoego_outlier_stats); at the end of a
+        # MI355X-specific knobs (not in the reference): operand precision and the noise source (DESIGN.md 3, 3c).
+        # Precisions: 9 (PREC_I8X3_FC) = every contraction of the layers on int8 slices, int8-only activations between the kernels of
+        # a step — the fastest; 8 (PREC_I8X3) = fc, linear_out and the residuals on split-bf16; 3 (PREC_BF16X3) = split-bf16
+        # everywhere (~2e-5 on one forward on every checkpoint measured, ~85 % more time per step than 9).  The int8 precisions are
+        # 16-bit FIXED point per row: what they lose depends on the checkpoint, so "auto" (default) is decided by MEASUREMENT and
+        # remembered (plan.py): the ladder 9 as is -> 9 prepared -> 9 prepared + fc24 -> 8 as is -> 8 prepared -> 3, each candidate
+        # against split-bf16 on a probe batch (stage 1: the end of a chain + two forwards; stage 2: whole chains on 32 windows);
+        # the verdict is cached on disk per checkpoint; a chain-level call shorter than the probe runs split-bf16 unprobed; under
+        # torch.distributed the sharded entry points (dist.py) make all ranks pack rank 0's plan.  `hip_precision_used` /
+        # `hip_precision_probe` tell what was picked, from where ("probe" / "cache" / "small job" / "group rank 0 (...)"), and what
+        # was measured.  While an int8 precision runs, the LayerNorm epilogues record their largest row maxima; at the end of a
         # chain `_outlier_guard` compares them with what the probe saw and, beyond that envelope, re-measures on the chain's own
-        # tensors and steps "auto" down to 3 (DESIGN.md 3c).
+        # tensors and steps "auto" down to 3.
         self.hip_precision = "auto"
         self.hip_precision_used = None
-        self.hip_precision_probe = None   # what the pack-time probe measured: {"errors": {9: .., 8: ..}, "limit": .., "row_max": [..]}
-        self.hip_probe_at_pack = True     # False: skip the probe (auto = 9, absolute envelope for the runtime guard)
-        self.hip_probe_full_chain = True  # False: 'auto' trusts stage 1 of the probe (saves ~0.6 s per pack at 1000 steps)
+        self.hip_precision_probe = None   # the plan's measurement: {"errors": {"9 as is": .., "9 as is, full chain": ..}, "limit", "chain_limit", "row_max", "form", "source", ..}
+        self.hip_probe_at_pack = True     # False: no measurement at all (auto = 9, absolute envelope for the runtime guard)
+        self.hip_probe_full_chain = True  # False: 'auto' trusts stage 1 of the probe (saves ~1 s per measured checkpoint at 1000 steps)
         self.hip_fc24 = True              # 'auto' may run precision 9 with fc's weights as three int8 slices (FLAG_FC24, ~+10 % per step) before falling back to 8
         self.hip_int8_prep = "auto"       # pack-time preparation of int8 precisions (precision.py): "auto" = only when the plain packing fails the probe; "always"; "never"
+        self.hip_plan_cache = True        # remember / reuse the verdict on disk ($EGOEGO_HIP_CACHE, default ~/.cache/egoego_hip; plan.py)
+        self.hip_plan_override = None     # tools/tests: (precision, prepared, flags) — pack exactly this form (measured and reported, never rejected)
         self.hip_outlier_guard = True     # False: no read-back (and no stream sync) at the end of a chain
         self.hip_outlier_seen = None      # per LayerNorm site, the largest row maximum of the last guarded chain
         self.hip_graph = True        # replay one captured step per chain (hipGraph); False launches every kernel
@@ -242,6 +249,7 @@ class CondGaussianDiffusion(nn.Module):
         dev = self.betas.device
         return (str(dev), self.hip_precision, bool(self.hip_graph), self.objective, int(self.betas.shape[0]),
                 self.hip_int8_prep, bool(self.hip_probe_at_pack), bool(self.hip_probe_full_chain), bool(self.hip_fc24),
+                None if self.hip_plan_override is None else tuple(self.hip_plan_override), bool(self.hip_plan_cache),
                 tuple((p.data_ptr(), p._version) for p in self._packed_tensors()))
 
     @torch.no_grad()
@@ -271,6 +279,7 @@ class CondGaussianDiffusion(nn.Module):
         self._slot.engine_masked, self._slot.plan = None, None
         self._slot.noise_buf = None
         self._slot.envelope, self._slot.demoted, self._slot.force_repack = None, False, False
+        self._slot.unprobed_work = 0
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -283,170 +292,120 @@ class CondGaussianDiffusion(nn.Module):
             self.invalidate_engine()
         return out
 
-    def hip_engine(self, verify=False, masked=False):
+    def hip_engine(self, verify=False, masked=False, job=None, group=None):
         """The HIP context for the module's current device/weights (packed lazily, re-packed when parameters change
         or the module moves).  verify=True (every chain-level entry point: sample, p_sample_loop, ddim_sample, the
         sliding-window harness) additionally compares a device-side checksum of the weights with the one taken when
         they were packed.  masked=True: the context for calls that carry a padding mask — the same precision, but packed without
-        the mean shift of the LayerNorm rows when the main context has it (precision.py: a mask zeroes rows AFTER the shift)."""
+        the mean shift of the LayerNorm rows when the main context has it (precision.py: a mask zeroes rows AFTER the shift).
+        job=(windows, frames, steps): the chain-level call this context is for — under hip_precision="auto" a job shorter than the
+        precision probe runs split-bf16 unprobed (plan.py).  group: a torch.distributed process group whose ranks must all sample
+        from ONE plan (dist.py passes it): every rank reports whether its packed copy is stale, and if any is, group rank 0
+        resolves the plan and broadcasts it (prepared tensors included) — call it on every rank of the group."""
         dev = self.betas.device
         if dev.type != "cuda":
             raise _lib.EgoEgoHipError(
                 "CondGaussianDiffusion sampling runs on the MI355X HIP path only: move the module to a ROCm "
                 f"device first (it is on {dev}); there is no CPU fallback")
+        slot = self._slot
         key = self._engine_key()
-        fp = self._weights_fingerprint() if verify else None
-        stale = (self._slot.engine is None or self._slot.key != key or (verify and self._slot.fingerprint != fp)
-                 or self._slot.force_repack)
+        fp = self._weights_fingerprint() if (verify or group is not None) else None
+        stale = (slot.engine is None or slot.key != key or (fp is not None and slot.fingerprint != fp) or slot.force_repack
+                 or (slot.plan is not None and slot.plan["source"] == "small job" and job is not None and not plan_mod.is_small_job(self, job)))
+        synced = group is not None and _world(group) > 1
+        if synced:
+            # one all_reduce, always: is any rank's copy stale, and do all ranks hold the same weights?
+            got = plan_mod.group_max([1.0 if stale else 0.0, fp[0], -fp[0], fp[1], -fp[1]], group)
+            if got[1] != -got[2] or got[3] != -got[4]:
+                raise _lib.EgoEgoHipError("the ranks of the process group hold different weights (checksums differ): window-sharded "
+                                          "sampling needs the same checkpoint on every rank")
+            stale = got[0] > 0
         if stale:
-            for e in (self._slot.engine, self._slot.engine_masked):
+            for e in (slot.engine, slot.engine_masked):
                 if e is not None:
                     e.close()
-            self._slot.engine = self._slot.engine_masked = None
-            if not self._slot.force_repack:
-                self._slot.demoted = False  # new weights / device / settings: measured afresh
-            self._slot.force_repack = False
+            slot.engine = slot.engine_masked = None
+            if not slot.force_repack:
+                slot.demoted = False  # new weights / device / settings: measured afresh
+            slot.force_repack = False
             if self.objective not in ("pred_noise", "pred_x0"):
                 raise ValueError(f"unknown objective {self.objective}")
-            self._slot.plan = plan = self._resolve_precision()
-            self.hip_precision_used = plan["precision"]
-            self._slot.engine = HipEngine(_engine_cfg(self), plan["sd"] if plan["sd"] is not None else self.state_dict(), dev, plan["precision"],
-                                          (0 if self.hip_graph else _lib.FLAG_NO_GRAPH) | plan.get("flags", 0), row_shift=plan["row_shift"])
-            self._slot.key = key
-            self._slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
-        if masked and self._slot.plan["row_shift"]:
-            if self._slot.engine_masked is None:
-                self._slot.engine_masked = HipEngine(_engine_cfg(self), self._slot.plan["sd_unshifted"], dev, self._slot.plan["precision"],
-                                                     (0 if self.hip_graph else _lib.FLAG_NO_GRAPH) | self._slot.plan.get("flags", 0))
-            return self._slot.engine_masked
-        return self._slot.engine
+            if synced:
+                import torch.distributed as tdist
+                plan = plan_mod.resolve(self, job, fp) if tdist.get_rank(group) == 0 else None
+                plan = plan_mod.group_broadcast(plan, group)
+                plan = dict(plan, source=plan["source"] if tdist.get_rank(group) == 0 else f"group rank 0 ({plan['source']})")
+            else:
+                plan = plan_mod.resolve(self, job, fp)
+            slot.plan = plan
+            plan_mod.adopt(self, plan)
+            slot.engine = HipEngine(_engine_cfg(self), plan["sd"] if plan["sd"] is not None else self.state_dict(), dev, plan["precision"],
+                                    (0 if self.hip_graph else _lib.FLAG_NO_GRAPH) | plan["flags"], row_shift=plan["row_shift"])
+            slot.key = key
+            slot.fingerprint = fp if fp is not None else self._weights_fingerprint()
+        if masked and slot.plan["row_shift"]:
+            if slot.engine_masked is None:
+                slot.engine_masked = HipEngine(_engine_cfg(self), plan_mod.masked_state(slot.plan, self.state_dict()), dev, slot.plan["precision"],
+                                               (0 if self.hip_graph else _lib.FLAG_NO_GRAPH) | slot.plan["flags"])
+            return slot.engine_masked
+        return slot.engine
 
-    PROBE_LIMIT = 5e-4       # stage 1 (cheap, every candidate): largest difference from split-bf16 on the end of a chain + two forwards:
-                             # half the 1e-3 bar — a short chain on other data ran 1.5-1.7x its probe figure (trained-like checkpoint)
-    PROBE_TAIL = 50          # ancestral steps of stage 1's end-of-chain run
-    CHAIN_LIMIT = 5.5e-4     # stage 2 ("auto", the candidate that passed stage 1): the WHOLE num_timesteps chain from noise on the probe batch
-                             # (the largest of 4 windows) against split-bf16 (itself ~1e-4 from fp32 at the end of 1000 steps).  A trained
-                             # denoiser's full chain ran 3.5-4.7x its stage-1 figure (1.5e-4 -> 5.1e-4 / 7.0e-4 for two draws, round 4), and
-                             # the error is heavy-tailed over windows: against the fp32 oracle, 8 windows of the trained-like checkpoint ended
-                             # 3.7-8.1e-4 away in precision 9 prepared (this figure: 7.0e-4) and 1.8-4.1e-4 in 8 prepared
-                             # (tools/trained_like_full_chain.py) — a batch of 256 would leave the bar in the first and not in the second
+    # the limits of the pack-time measurement live in plan.py (kept here for callers that read them off the module)
+    PROBE_LIMIT = plan_mod.PROBE_LIMIT
+    PROBE_TAIL = plan_mod.PROBE_TAIL
+    CHAIN_LIMIT = plan_mod.CHAIN_LIMIT
     ENVELOPE_MARGIN = 1.5    # the runtime guard re-measures when a LayerNorm row maximum exceeds this multiple of what the probe validated
     ENVELOPE_ABSOLUTE = 8.0  # ... or this value when no probe ran (rows of the reference's initialisation peak at 4-5)
 
-    def _resolve_precision(self):
-        """What the HIP context is packed from: {"precision", "sd" (None = the module's own state dict), "row_shift", "sd_unshifted",
-        "prepared"}.  The int8-slice precisions are 16-bit FIXED point (one scale per activation row / weight row); what they lose
-        depends on the checkpoint — on trained weights mostly the weight grid under a sharp attention and LayerNorm rows with a
-        near-constant massive feature (precision.py).  So nothing is assumed: `hip_precision = "auto"` MEASURES, on
-        every (re)pack, each candidate against split-bf16 on a probe batch (`PrecisionProbe.error`: the end of a chain + two
-        forwards) and takes the first one within PROBE_LIMIT of
-            9 as is  ->  9 prepared  ->  8 as is  ->  8 prepared  ->  3 (with a RuntimeWarning),
-        "prepared" = the pack-time transformations of precision.py (mean-shifted LayerNorm rows folded into biases, error-compensating
-        rounding of the int8 weights on the library's own grid: same kernels, same speed; ~3 s more packing per candidate (measured on the GPU box), paid only when the plain
-        packing fails the probe; `hip_int8_prep` = "always" / "never" forces it on / off).  An explicit int8 precision is kept (prepared
-        if that is what passes) and warned about when neither form is within the limit.  The outcome is in `hip_precision_used` /
-        `hip_precision_probe`."""
-        want = self.hip_precision
-        self._slot.envelope = None
-        plain = {"precision": want, "sd": None, "row_shift": None, "sd_unshifted": None, "prepared": False, "flags": 0, "form": "as is"}
-        if want != "auto" and want not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
-            self.hip_precision_probe = None
-            return plain
-        if want == "auto" and self._slot.demoted:
-            return dict(plain, precision=_lib.PREC_BF16X3)
-        if not self.hip_probe_at_pack:
-            self.hip_precision_probe = None
-            return dict(plain, precision=_lib.PREC_I8X3_FC if want == "auto" else want)
-        cands = (_lib.PREC_I8X3_FC, _lib.PREC_I8X3) if want == "auto" else (want,)
-        # (prepared?, flags): as is, prepared, and — precision 9 under "auto" only — prepared with fc's weights as three int8 slices
-        forms = {"auto": ((False, 0), (True, 0)), "always": ((True, 0),), "never": ((False, 0),)}[self.hip_int8_prep]
-        probe = PrecisionProbe(self, tail=self.PROBE_TAIL)
-        errors, calib, pick, best = {}, None, None, None
-        try:
-            sd = probe.sd
-            for prec in cands:
-                pforms = forms
-                if want == "auto" and prec == _lib.PREC_I8X3_FC and self.hip_int8_prep == "auto" and self.hip_fc24:
-                    pforms = forms + ((True, _lib.FLAG_FC24),)
-                for prepared, flags in pforms:
-                    fname = ("prepared" if prepared else "as is") + (" + fc24" if flags & _lib.FLAG_FC24 else "")
-                    if prepared:
-                        calib = probe.calibration() if calib is None else calib
-                        fc24 = bool(flags & _lib.FLAG_FC24)
-                        sd_s, row_shift = prepare_int8_state(sd, calib, prec, shift=True, fc24=fc24)
-                        # for padding-mask calls: the same rounded weights and K / V shifts, no LayerNorm-row shift (no second rounding pass)
-                        sd_u, _ = prepare_int8_state({k: (sd_s[k] if k.endswith(".weight") else v) for k, v in sd.items()}, calib, prec,
-                                                     shift=False, rounding=False, fc24=fc24)
-                    else:
-                        sd_s, row_shift, sd_u = sd, None, None
-                    err, row_max = probe.error(sd_s, prec, row_shift, flags)
-                    errors[(prec, fname)] = err
-                    cand = {"precision": prec, "sd": sd_s if prepared else None, "row_shift": row_shift, "sd_unshifted": sd_u, "prepared": prepared,
-                            "flags": flags, "form": fname}
-                    if best is None or err < best[0]:
-                        best = (err, cand, row_max)
-                    if err <= self.PROBE_LIMIT:
-                        if want == "auto" and self.hip_probe_full_chain:
-                            # stage 2, for the candidate that would run: the WHOLE chain from noise against split-bf16
-                            cerr = probe.chain_error(sd_s, prec, row_shift, flags)
-                            errors[(prec, fname + ", full chain")] = cerr
-                            if cerr > self.CHAIN_LIMIT:
-                                continue
-                        pick = cand
-                        break
-                if pick is not None:
-                    break
-        finally:
-            probe.close()
-        explicit_best = want != "auto" and pick is None
-        self.hip_precision_probe = {"errors": {f"{p} {f}": e for (p, f), e in errors.items()}, "limit": self.PROBE_LIMIT,
-                                    "row_max": row_max if pick is not None else (best[2] if explicit_best else None),
-                                    "prepared": bool(pick["prepared"] if pick else (explicit_best and best[1]["prepared"])),
-                                    "form": (pick["form"] if pick else (best[1]["form"] if explicit_best else None))}
-        if pick is not None:
-            self._slot.envelope = row_max
-            return pick
-        shown = ", ".join(f"precision {p} {f}: {e:.1e}" for (p, f), e in errors.items())
-        if want == "auto":
-            warnings.warn(
-                f"hip_precision='auto': the int8-slice precisions differ from split-bf16 by more than {self.PROBE_LIMIT:.0e} on the probe "
-                f"batch for this checkpoint ({shown}); falling back to split-bf16 (3), ~85 % more time per step "
-                f"(tools/precision_compare.py measures each precision on it)", RuntimeWarning, stacklevel=4)
-            return dict(plain, precision=_lib.PREC_BF16X3)
-        warnings.warn(
-            f"hip_precision={want} differs from split-bf16 by more than {self.PROBE_LIMIT:.0e} on the probe batch for this checkpoint "
-            f"({shown}; the limit is half the 1e-3 bar): it may leave the bar; set model.hip_precision = 'auto' or {_lib.PREC_BF16X3}",
-            RuntimeWarning, stacklevel=4)
-        self._slot.envelope = best[2]
-        return best[1]  # the explicit precision is kept, in the packing that measured best
+    def _note_job(self, job):
+        """A chain-level call ran on a context packed for a small job (split-bf16, unprobed): add its work up (plan.is_small_job)."""
+        if self._slot.plan is not None and self._slot.plan["source"] == "small job":
+            self._slot.unprobed_work += job[0] * job[2]
 
     @torch.no_grad()
-    def _outlier_guard(self, eng, x, x_cond):
+    def _outlier_guard(self, eng, x, x_cond, group=None):
         """End of a chain in an int8 precision: read the LayerNorm row maxima the chain produced (one stream sync).  Inside the
         envelope the pack-time probe validated (x ENVELOPE_MARGIN) nothing else happens.  Beyond it the probe is repeated on the
         chain's OWN tensors (its final x re-noised and walked down again): within PROBE_LIMIT the envelope grows to what was seen;
         outside it a RuntimeWarning says so and `hip_precision = "auto"` steps down to split-bf16 from the next call on (this
-        chain's result stands: it is what was measured)."""
-        if not self.hip_outlier_guard or self.hip_precision_used not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC) or x.shape[0] == 0:
+        chain's result stands: it is what was measured).
+        group (dist.py): the decision is COLLECTIVE — the row maxima are all-reduced (MAX) over the ranks, group rank 0 (which holds
+        the global batch's first windows, like a single rank would) re-measures, and its verdict is broadcast: every rank steps
+        down, or none does.  Every rank of the group must call this, with an empty shard too."""
+        if not self.hip_outlier_guard or self.hip_precision_used not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
             return
-        seen = eng.outlier_stats(x.shape[0], x.shape[1], reset=True)
+        synced = group is not None and _world(group) > 1
+        if x.shape[0] == 0 and not synced:
+            return
+        n_sites = min(_lib.OUTLIER_SITES, 2 * self.denoise_fn.n_dec_layers)
+        seen = eng.outlier_stats(x.shape[0], x.shape[1], reset=True) if x.shape[0] else [0.0] * n_sites
+        if synced:
+            seen = plan_mod.group_max(seen, group)
         self.hip_outlier_seen = seen
         env = self._slot.envelope
         lim = [self.ENVELOPE_ABSOLUTE] * len(seen) if env is None else [self.ENVELOPE_MARGIN * max(v, 1e-30) for v in env]
         if all(s <= l for s, l in zip(seen, lim)):
             return
         prec, plan = self.hip_precision_used, self._slot.plan
-        n = min(int(x.shape[0]), 8)
-        probe = PrecisionProbe(self, probe=(x[:n], x_cond[:n]), tail=self.PROBE_TAIL)
-        try:
-            psd = plan["sd"] if plan["sd"] is not None else probe.sd
-            err, _ = probe.error(psd, prec, plan["row_shift"], plan.get("flags", 0))
-            ok = err <= self.PROBE_LIMIT
-            if ok and self.hip_probe_full_chain:
-                err = probe.chain_error(psd, prec, plan["row_shift"], plan.get("flags", 0))
-                ok = err <= self.CHAIN_LIMIT
-        finally:
-            probe.close()
+        measure = True
+        if synced:
+            import torch.distributed as tdist
+            measure = tdist.get_rank(group) == 0
+        ok, err = True, 0.0
+        if measure and x.shape[0]:
+            n = min(int(x.shape[0]), 8)
+            probe = PrecisionProbe(self, probe=(x[:n], x_cond[:n]), tail=self.PROBE_TAIL)
+            try:
+                psd = plan["sd"] if plan["sd"] is not None else probe.sd
+                err, _ = probe.error(psd, prec, plan["row_shift"], plan["flags"])
+                ok = err <= self.PROBE_LIMIT
+                if ok and self.hip_probe_full_chain:
+                    err, _ = probe.chain_error(psd, prec, plan["row_shift"], plan["flags"])
+                    ok = err <= self.CHAIN_LIMIT
+            finally:
+                probe.close()
+        if synced:
+            ok, err = plan_mod.group_broadcast((ok, err), group)
         if ok:
             self._slot.envelope = [max(a, b) for a, b in zip(seen, env)] if env is not None else list(seen)
             return
@@ -523,7 +482,8 @@ class CondGaussianDiffusion(nn.Module):
         consumed in the reference's order (sampling_rng='torch') or the per-step noise is drawn in-kernel
         (sampling_rng='philox').
         """
-        eng = self.hip_engine(verify=True, masked=padding_mask is not None)
+        job = (int(shape[0]), int(shape[1]), int(self.num_timesteps))
+        eng = self.hip_engine(verify=True, masked=padding_mask is not None, job=job)
         device = self.betas.device
         S = self.num_timesteps
         if noise is not None:
@@ -549,6 +509,7 @@ class CondGaussianDiffusion(nn.Module):
             self._torch_rng_chain(eng, x, x_cond, S, pfx, padding_mask)
         else:
             raise ValueError(f"unknown sampling_rng {self.sampling_rng}")
+        self._note_job(job)
         self._outlier_guard(eng, x, x_cond)
         return x
 
@@ -584,7 +545,8 @@ class CondGaussianDiffusion(nn.Module):
         """DDIM on a uniform stride of the training timesteps (eta=0: deterministic; eta > 0 draws in-kernel Philox
         noise keyed by `philox_seed`; eta=1 with n_steps=num_timesteps is the ancestral chain).  Not part of the
         reference (it only has the full ancestral chain); provided for BASELINE config 4."""
-        eng = self.hip_engine(verify=True)
+        job = (int(x_start.shape[0]), int(x_start.shape[1]), int(n_steps))
+        eng = self.hip_engine(verify=True, job=job)
         device = self.betas.device
         if noise is not None:
             x, cn = self._f32c(noise["x_T"].to(device)).clone(), noise["cond"].to(device)
@@ -593,6 +555,7 @@ class CondGaussianDiffusion(nn.Module):
         x_cond = self._f32c(x_start * (1.0 - cond_mask) + cond_mask * cn)
         ts = sorted({int(round(v)) for v in np.linspace(0, self.num_timesteps - 1, n_steps)}, reverse=True)
         eng.ddim_loop_(x, x_cond, ts, eta=eta, seed=self.philox_seed)
+        self._note_job(job)
         self._outlier_guard(eng, x, x_cond)
         return x
 

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    # the precision verdicts the GPU tests measure are remembered for the SESSION only (plan.py's disk cache, shared with the bench.py /
+    # tools subprocesses the tests start): nothing is read from, or left in, the home directory
+    if "EGOEGO_HIP_CACHE" not in os.environ:
+        import tempfile
+        os.environ["EGOEGO_HIP_CACHE"] = tempfile.mkdtemp(prefix="egoego_hip_cache_")
 
 
 @pytest.fixture(scope="session")

@@ -216,3 +216,118 @@ def test_harness_sharded_two_ranks_on_one_gpu_match_one_rank_bit_for_bit(tmp_pat
     a, _ = run(2, 2, 1, "bs_one")
     b, _ = run(2, 2, 2, "bs_two")
     assert a["local_aa"].shape == (4, 140, 22, 3) and np.array_equal(a["local_aa"], b["local_aa"]) and np.array_equal(a["root_trans"], b["root_trans"])
+
+
+# ------------------------------------------------------------------------------------------ one plan for all ranks (plan.py)
+def _massive_feature_weights(T=120):
+    """The checkpoint of test_runtime_outlier_guard_trips...: two output features of every pos_ffn.w_2 are 40x the rest."""
+    from egoego_release_amd import ModelConfig, make_weights
+    cfg = ModelConfig(max_timesteps=T + 1)
+    sd = make_weights(cfg, 0)
+    for k in list(sd):
+        if k.endswith("layer_norm.weight"):
+            sd[k] = torch.ones_like(sd[k])
+        if k.endswith("layer_norm.bias"):
+            sd[k] = torch.zeros_like(sd[k])
+        if k.endswith("pos_ffn.w_2.weight"):
+            sd[k] = sd[k].clone()
+            sd[k][[17, 301]] *= 40.0
+    return cfg, sd
+
+
+def _hot_gain_weights(T=120):
+    from egoego_release_amd import ModelConfig, make_weights
+    cfg = ModelConfig(max_timesteps=T + 1)
+    sd = make_weights(cfg, 0)
+    for k in sd:
+        if k.endswith("layer_norm.weight"):
+            sd[k] = sd[k].clone()
+            sd[k][:6] *= 25.0
+    return cfg, sd
+
+
+def _plan_run(rank, world, out):
+    """Both halves of the test, on `world` ranks (world = 1: no process group): (a) a chain whose LayerNorm monitors trip the runtime
+    guard — with the read-back of group rank 0 masked so that ONLY the other rank sees it; (b) a checkpoint whose plan is a
+    PREPARED packing, resolved through the group."""
+    import warnings
+    from egoego_release_amd import make_head_windows, _lib
+    from egoego_release_amd.engine import HipEngine
+    from egoego_release_amd.model import CondGaussianDiffusion
+    torch.cuda.set_device(0)
+    res = {}
+    # ---- (a) the guard's verdict is collective
+    cfg, sd = _massive_feature_weights()
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m.hip_probe_at_pack = False  # "auto" starts on precision 9 with the absolute envelope
+    m = m.cuda()
+    m.num_timesteps = 6
+    xs, cm = make_head_windows(4, 120, seed=2)
+    g = torch.Generator().manual_seed(31)
+    noise = {"x_T": torch.randn(xs.shape, generator=g), "cond": torch.randn(xs.shape, generator=g)}
+    real_stats = HipEngine.outlier_stats
+    if world > 1 and rank == 0:
+        def masked(self, B, T, reset=True):  # this rank's windows "look fine": left alone it would stay on precision 9
+            real_stats(self, B, T, reset)
+            return [1.0] * 8
+        HipEngine.outlier_stats = masked
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        first = D.sample_sharded(D.hip_sample_fn(m, seed=3), xs, cm, noise)
+    res["first_prec"], res["demoted"] = 9, bool(m._slot.demoted)
+    res["warned"] = any("beyond what the pack-time probe validated" in str(w.message) for w in rec)
+    second = D.sample_sharded(D.hip_sample_fn(m, seed=3), xs, cm, noise)
+    res["second_prec"] = int(m.hip_precision_used)
+    res["first"], res["second"] = first.cpu(), second.cpu()
+    HipEngine.outlier_stats = real_stats
+    # ---- (b) a prepared plan travels from group rank 0 to the others, tensors included
+    cfg, sd = _hot_gain_weights()
+    m2 = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m2.load_state_dict(sd, strict=False)
+    m2 = m2.cuda()
+    m2.num_timesteps = 6
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m2.hip_engine(verify=True, group=D._group_of(None))
+        third = D.sample_sharded(D.hip_sample_fn(m2, seed=4), xs, cm, noise)
+    pr = m2.hip_precision_probe
+    res["plan"] = (int(m2.hip_precision_used), pr["form"], pr["source"], m2._slot.plan["sd"] is not None)
+    res["third"] = third.cpu()
+    if m2._slot.plan["sd"] is not None:
+        res["w_sum"] = float(sum(v.double().sum() for k, v in m2._slot.plan["sd"].items() if k.endswith("w_q.weight")))
+    torch.save(res, out + str(rank))
+
+
+def _plan_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _plan_run(rank, world, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_all_ranks_sample_from_one_plan_and_step_down_together(tmp_path):
+    """plan.py / VERDICT r4 weak #3: two gloo ranks share the test box's GPU.  (a) The LayerNorm monitors of a massive-feature
+    checkpoint trip the runtime guard, but group rank 0's read-back is masked — alone it would stay on precision 9 while rank 1 steps
+    down, and the next call would no longer be shard-invariant.  With the collective verdict BOTH step down, and both calls equal the
+    one-rank run bit for bit.  (b) A checkpoint whose plan is a prepared packing: rank 0 measures, rank 1 packs rank 0's tensors."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out2, out1 = str(tmp_path / "two_"), str(tmp_path / "one_")
+    mp.spawn(_plan_worker, args=(2, port, out2), nprocs=2, join=True)
+    _plan_run(0, 1, out1)
+    one = torch.load(out1 + "0")
+    r0, r1 = torch.load(out2 + "0"), torch.load(out2 + "1")
+    assert one["demoted"] and one["warned"] and one["second_prec"] == 3, (one["demoted"], one["warned"], one["second_prec"])
+    for r in (r0, r1):
+        assert r["demoted"] and r["warned"] and r["second_prec"] == 3
+        assert torch.equal(r["first"], one["first"]) and torch.equal(r["second"], one["second"])
+    # (b): the same plan everywhere, resolved by group rank 0; rank 1 packed rank 0's prepared tensors, and the result is the one-rank one
+    assert r0["plan"][:2] == r1["plan"][:2] == one["plan"][:2], (r0["plan"], r1["plan"], one["plan"])
+    assert r1["plan"][2].startswith("group rank 0") and r0["plan"][2] in ("probe", "cache")
+    if one["plan"][3]:
+        assert r0["w_sum"] == r1["w_sum"] == one["w_sum"]
+    assert torch.equal(r0["third"], one["third"]) and torch.equal(r1["third"], one["third"])

@@ -247,6 +247,7 @@ def test_runtime_outlier_guard_trips_on_massive_features_and_steps_down():
         warnings.simplefilter("ignore")
         mp = _build(sd)
         mp.num_timesteps = S
+        mp.hip_engine()  # (measure now: a 2-window x 6-step chain alone is a "small job" and would run split-bf16 unprobed, plan.py)
         got = mp.sample(xs.cuda(), cm.cuda(), noise=nz).cpu()
     print("probe on: picked", mp.hip_precision_used, mp.hip_precision_probe)
     assert float((got - x).abs().max()) < POSE_TOL
@@ -261,6 +262,7 @@ def test_guards_are_quiet_and_cheap_on_the_reference_initialisation():
         m = _build(sd)
         m.num_timesteps = 5
         m.sampling_rng = "philox"
+        m.hip_engine()  # measured (or its verdict read from the plan cache) here; the 3-window x 5-step chain itself is a small job
         a = m.sample(xs.cuda(), cm.cuda())
         assert m.hip_precision_used == _lib.PREC_I8X3_FC
         seen, env = m.hip_outlier_seen, m._slot.envelope
@@ -276,9 +278,60 @@ def test_guards_are_quiet_and_cheap_on_the_reference_initialisation():
         b2 = m.sample(xs.cuda(), cm.cuda())
         assert torch.equal(b1, b2)
     # the pack-time probe does not touch torch's global generators (sample() consumes them in the reference's order)
-    m2 = _build(sd)  # (constructing the module draws its initial weights from the global generator, like the reference's)
+    m2 = _build(sd, hip_plan_cache=False)  # (constructing the module draws its initial weights from the global generator, like the reference's)
     torch.manual_seed(123)
     c0, g0 = torch.get_rng_state(), torch.cuda.get_rng_state()
     m2.hip_engine()
     assert torch.equal(c0, torch.get_rng_state()) and torch.equal(g0, torch.cuda.get_rng_state())
     assert m2.hip_precision_probe["errors"]["9 as is"] < m2.PROBE_LIMIT and not m2.hip_precision_probe["prepared"]
+    assert m2.hip_precision_probe["source"] == "probe" and m.hip_precision_probe["source"] in ("probe", "cache")
+
+
+def test_small_jobs_run_split_bf16_unprobed_and_the_verdict_is_cached(tmp_path, monkeypatch):
+    """plan.py: under "auto" a chain-level call shorter than the precision probe (the reference's own use: sample_bs = 1, two
+    windows, run_egoego.py:146) runs split-bf16 with no measurement; a job of the metric's size measures, and remembers the verdict
+    on disk: a fresh module on the same weights packs it without measuring; after enough unprobed work the probe runs after all."""
+    from egoego_release_amd import plan
+    monkeypatch.setenv("EGOEGO_HIP_CACHE", str(tmp_path / "cache"))
+    cfg = ModelConfig(max_timesteps=T + 1)
+    sd = make_weights(cfg, 7)
+    xs, cm = make_head_windows(2, T, seed=5)
+    m = _build(sd)
+    m.num_timesteps = 20
+    m.sampling_rng = "philox"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        torch.manual_seed(5)  # (x_T and the condition noise come from torch's generator)
+        a = m.sample(xs.cuda(), cm.cuda())
+    assert m.hip_precision_used == _lib.PREC_BF16X3 and m.hip_precision_probe["source"] == "small job" and "skipped" in m.hip_precision_probe
+    assert m._slot.unprobed_work == 2 * 20
+    assert not os.path.isdir(tmp_path / "cache") or not os.listdir(tmp_path / "cache")  # nothing was measured: nothing to remember
+    ref = _build(sd, _lib.PREC_BF16X3)
+    ref.num_timesteps, ref.sampling_rng = 20, "philox"
+    torch.manual_seed(5)
+    assert torch.equal(a, ref.sample(xs.cuda(), cm.cuda()))  # it IS the split-bf16 chain
+    m.num_timesteps = 1000
+    m.hip_engine(verify=True, job=(64, T, 1000))  # what a 64-window sample() asks for: not a small job -> measured now
+    assert m.hip_precision_used == _lib.PREC_I8X3_FC and m.hip_precision_probe["source"] == "probe"
+    files = os.listdir(tmp_path / "cache")
+    assert len(files) == 1 and files[0].startswith("plan_")
+    # a second module (another process would do the same): the verdict comes from the file, even for a small job
+    import time
+    m2 = _build(sd)
+    m2.num_timesteps, m2.sampling_rng = 20, "philox"
+    t1 = time.perf_counter()
+    torch.manual_seed(5)
+    b = m2.sample(xs.cuda(), cm.cuda())
+    dt = time.perf_counter() - t1
+    assert m2.hip_precision_used == _lib.PREC_I8X3_FC and m2.hip_precision_probe["source"] == "cache", m2.hip_precision_probe
+    assert m2.hip_precision_probe["errors"] == m.hip_precision_probe["errors"]
+    print(f"pack + 20-step chain from a cached verdict: {dt:.2f} s")
+    assert float((a - b).abs().max()) < 1e-3
+    # unprobed work adds up: beyond PROBE_AFTER_WINDOW_STEPS the next small job measures
+    m3 = _build(make_weights(cfg, 8), hip_plan_cache=False)
+    m3.num_timesteps, m3.sampling_rng = 20, "philox"
+    m3.sample(xs.cuda(), cm.cuda())
+    assert m3.hip_precision_used == _lib.PREC_BF16X3
+    m3._slot.unprobed_work = plan.PROBE_AFTER_WINDOW_STEPS
+    m3.sample(xs.cuda(), cm.cuda())
+    assert m3.hip_precision_used == _lib.PREC_I8X3_FC and m3.hip_precision_probe["source"] == "probe"

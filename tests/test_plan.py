@@ -1,0 +1,141 @@
+"""plan.py on the CPU: the ladder `auto` walks, the small-job rule, the on-disk verdict cache, and the two collectives that make all
+ranks of a process group sample from ONE plan (gloo, world_size 2) — plus the 8-rank form of the path's one all_gather.
+(What the ladder MEASURES needs the GPU: tests/test_gpu_trained_like.py, tests/test_gpu_parity.py.)"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from egoego_release_amd import _lib, plan
+from egoego_release_amd import dist as D
+from egoego_release_amd import ModelConfig
+from egoego_release_amd.model import CondGaussianDiffusion
+
+
+def _model():
+    return CondGaussianDiffusion(**ModelConfig(max_timesteps=31).ctor_kwargs())
+
+
+def test_ladder_order_and_knobs():
+    m = _model()
+    F = _lib.FLAG_FC24
+    assert plan.ladder(m) == [(9, False, 0), (9, True, 0), (9, True, F), (8, False, 0), (8, True, 0)]
+    m.hip_fc24 = False
+    assert plan.ladder(m) == [(9, False, 0), (9, True, 0), (8, False, 0), (8, True, 0)]
+    m.hip_int8_prep = "never"
+    assert plan.ladder(m) == [(9, False, 0), (8, False, 0)]
+    m.hip_int8_prep, m.hip_precision = "always", 8
+    assert plan.ladder(m) == [(8, True, 0)]
+    m.hip_plan_override = (9, True, F)
+    assert plan.ladder(m) == [(9, True, F)]
+    assert plan.form_name(True, F) == "prepared + fc24" and plan.form_name(False, 0) == "as is"
+
+
+def test_small_job_rule():
+    m = _model()
+    assert plan.is_small_job(m, (2, 120, 1000))            # the reference's own use: two windows of one clip
+    assert not plan.is_small_job(m, (256, 120, 1000)) and not plan.is_small_job(m, (64, 120, 1000)) and not plan.is_small_job(m, None)
+    assert plan.is_small_job(m, (256, 120, 20))            # a 20-step slice of a big batch is short too
+    m._slot.unprobed_work = plan.PROBE_AFTER_WINDOW_STEPS  # ... until enough of them have run unprobed
+    assert not plan.is_small_job(m, (2, 120, 1000))
+    m._slot.unprobed_work = 0
+    m.hip_precision = 9                                    # an explicit precision is never replaced
+    assert not plan.is_small_job(m, (2, 120, 1000))
+    # resolve() without a probe never touches the GPU: explicit split-bf16, probe off, demoted
+    m.hip_precision = _lib.PREC_BF16X3
+    assert plan.resolve(m, None)["precision"] == 3 and plan.resolve(m, None)["source"] == "explicit"
+    m.hip_precision, m.hip_probe_at_pack = "auto", False
+    assert plan.resolve(m, (2, 120, 1000))["precision"] == 9 and plan.resolve(m, None)["source"] == "no probe"
+    m.hip_probe_at_pack = True
+    m._slot.demoted = True
+    assert plan.resolve(m, None)["precision"] == 3
+
+
+def test_verdict_cache_round_trip(tmp_path, monkeypatch):
+    monkeypatch.setenv("EGOEGO_HIP_CACHE", str(tmp_path / "c"))
+    m = _model()
+    fp = (1.25, 3.5)
+    k1 = plan.cache_key(m, fp)
+    assert k1 == plan.cache_key(m, fp) and k1 != plan.cache_key(m, (1.25, 3.5000001))
+    m.hip_fc24 = False
+    assert plan.cache_key(m, fp) != k1  # a knob that shapes the ladder is part of the key
+    m.hip_fc24 = True
+    assert plan.cache_load(k1) is None
+    p = dict(plan.plain_plan(9, "probe", {"errors": {"9 as is": 1e-4}}), sd={"w": torch.arange(6.0).reshape(2, 3)},
+             row_shift={"embed": torch.ones(4), (0, "attn_ln"): torch.zeros(4)}, prepared=True, form="prepared", envelope=[4.0] * 8)
+    plan.cache_store(k1, p)
+    got = plan.cache_load(k1)
+    assert got["precision"] == 9 and got["form"] == "prepared" and torch.equal(got["sd"]["w"], p["sd"]["w"])
+    assert torch.equal(got["row_shift"][(0, "attn_ln")], torch.zeros(4)) and got["envelope"] == [4.0] * 8
+    (tmp_path / "c" / f"plan_{k1}.pt").write_bytes(b"not a checkpoint")  # a damaged file is measured again, not trusted
+    assert plan.cache_load(k1) is None
+    monkeypatch.setenv("EGOEGO_HIP_CACHE", "off")
+    assert plan.cache_dir() is None and plan.cache_load(k1) is None
+    plan.cache_store(k1, p)  # (a no-op)
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _sync_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = D._group_of(None)
+    # the stale flag and the checksums of hip_engine(group=...): one all_reduce(MAX)
+    got = plan.group_max([1.0 if rank == 1 else 0.0, 7.125, -7.125], grp)
+    # the plan itself: rank 0's object (tensors included) reaches every rank
+    mine = dict(plan.plain_plan(9 if rank == 0 else 3, "probe"), sd={"w": torch.full((3,), float(rank))}) if rank == 0 else None
+    p = plan.group_broadcast(mine, grp)
+    ok, err = plan.group_broadcast((False, 7e-4) if rank == 0 else None, grp)
+    torch.save({"max": got, "prec": p["precision"], "w": p["sd"]["w"], "ok": ok, "err": err}, out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_group_helpers_two_gloo_ranks(tmp_path):
+    out = str(tmp_path / "r")
+    mp.spawn(_sync_worker, args=(2, _port(), out), nprocs=2, join=True)
+    for r in range(2):
+        d = torch.load(out + str(r))
+        assert d["max"] == [1.0, 7.125, -7.125]                 # rank 1's stale copy is everyone's business
+        assert d["prec"] == 9 and torch.equal(d["w"], torch.zeros(3))  # rank 0's plan, rank 0's tensors
+        assert d["ok"] is False and d["err"] == 7e-4
+
+
+def _fake_sampler(xs, cm, noise, window_offset):
+    idx = torch.arange(window_offset, window_offset + xs.shape[0], dtype=torch.float32)[:, None, None]
+    return noise["x_T"] * 0.5 + xs * (1 - cm) + idx
+
+
+def _eight_worker(rank, world, port, B, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(B, 5, 9, generator=g)
+    cm = (torch.rand(B, 5, 9, generator=g) > 0.5).float()
+    noise = {"x_T": torch.randn(B, 5, 9, generator=g), "cond": torch.randn(B, 5, 9, generator=g)}
+    res = D.sample_sharded(_fake_sampler, xs, cm, noise)
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_eight_gloo_ranks_even_and_ragged(tmp_path):
+    """`bench.py --gpus 8`'s data path with a stand-in sampler: B = 256 windows over 8 ranks (32 each: the gathered buffer IS the
+    result), B = 250 (ragged: 32 x 2 + 31 x 6) and B = 5 (three ranks sample nothing) — one all_gather_into_tensor each."""
+    for B in (256, 250, 5):
+        out = str(tmp_path / f"e{B}.pt")
+        mp.spawn(_eight_worker, args=(8, _port(), B, out), nprocs=8, join=True)
+        g = torch.Generator().manual_seed(0)
+        xs = torch.randn(B, 5, 9, generator=g)
+        cm = (torch.rand(B, 5, 9, generator=g) > 0.5).float()
+        noise = {"x_T": torch.randn(B, 5, 9, generator=g), "cond": torch.randn(B, 5, 9, generator=g)}
+        assert torch.equal(torch.load(out), _fake_sampler(xs, cm, noise, 0))
+    assert [D.shard_bounds(250, r, 8) for r in range(8)][:3] == [(0, 32), (32, 64), (64, 95)]

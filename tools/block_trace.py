@@ -14,11 +14,13 @@ _eglib.use_perfdebug_build()  # needs `python -m egoego_release_amd.build --perf
 from egoego_release_amd.model import CondGaussianDiffusion
 
 which = sys.argv[1] if len(sys.argv) > 1 else "ffn1"
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else _lib.PREC_BF16X3  # 9: `out` / `embed` trace the product kernels of precision 9
 B, T = 256, 120
 cfg = ModelConfig(max_timesteps=T + 1)
 m = CondGaussianDiffusion(**cfg.ctor_kwargs())
 m.load_state_dict(make_weights(cfg, 0), strict=False)
-m.hip_precision = _lib.PREC_BF16X3
+m.hip_precision = prec
+m.hip_probe_at_pack = False
 m = m.cuda()
 eng = m.hip_engine()
 lib = _lib.load()
@@ -39,7 +41,7 @@ torch.cuda.synchronize()
 lib.egoego_debug_trace_buffer(None)
 cyc = buf.cpu()[65536:].view(-1, 2)
 tr = buf.cpu()[:65536].view(-1, 4)
-n = {"ffn1": 512, "qkv": 3072, "fc_ln": 256, "ffn2_ln": 256, "embed": 512, "out": 256}[which]  # blocks of the LAST launch (earlier launches leave stale rows)
+n = {"ffn1": 512, "qkv": 3072, "fc_ln": 256, "ffn2_ln": 256, "embed": 512 if prec == _lib.PREC_BF16X3 else 256, "out": 256}[which]  # blocks of the LAST launch (earlier launches leave stale rows)
 tr = tr[:n]
 t0 = int(tr[:, 0].min())
 print(f"{which}: {n} blocks; kernel span {(int(tr[:, 2].max()) - t0) / 100:.1f} us")

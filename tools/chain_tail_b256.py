@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""The WHOLE 1000-step chain at the metric's own size: per-window error of what `auto` picks (and of the other int8 forms) at B = 256.
+
+For a checkpoint and window length: the full Philox chain on B windows of in-distribution data (synthetic.make_motion_windows) in
+every requested packing and in split-bf16 (precision 3) with the same seed; per-window max-abs against precision 3 — the maximum, the
+99th percentile, the median, the same over the first 64 windows (BASELINE configs[1]) — next to what the pack-time probe measured
+for that packing on ITS windows (plan.py stage 2), i.e. the ratio the probe's limit has to leave room for.  `--oracle N`: N of the
+windows with the oracle's injected draws against the fp32 CPU oracle as well (~20 s of CPU per window on the GPU box).
+
+    python tools/chain_tail_b256.py [--weights init,seed0,seed1,seed2] [--windows 120,196] [--batch 256] [--forms auto,9p,9pf,8p]
+                                    [--oracle 16] [--out profiles/r05_chain_tail_b256.txt]
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from egoego_release_amd import ModelConfig, make_weights, head_condition_mask, _lib  # noqa: E402
+from egoego_release_amd.model import CondGaussianDiffusion  # noqa: E402
+from egoego_release_amd.synthetic import make_motion_windows  # noqa: E402
+
+FORMS = {"auto": None, "9": (9, False, 0), "9p": (9, True, 0), "9pf": (9, True, _lib.FLAG_FC24), "8": (8, False, 0), "8p": (8, True, 0)}
+S = 1000
+
+
+def build(sd, T, form, cache=True):
+    cfg = ModelConfig(max_timesteps=T + 1)
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m.hip_plan_cache = cache
+    if form == "3":
+        m.hip_precision = _lib.PREC_BF16X3
+    elif FORMS[form] is not None:
+        m.hip_plan_override = FORMS[form]
+    return m.cuda()
+
+
+def stats(d):
+    d = d.double()
+    q = torch.quantile(d, torch.tensor([0.5, 0.99], dtype=torch.float64))
+    return {"max": float(d.max()), "p99": float(q[1]), "median": float(q[0]), "argmax": int(d.argmax())}
+
+
+def philox_chain(m, x_T, x_cond, seed):
+    eng = m.hip_engine(verify=True)
+    x = x_T.clone()
+    eng.sample_loop_(x, x_cond, S - 1, S, noise_mode=_lib.NOISE_PHILOX, seed=seed)
+    torch.cuda.synchronize()
+    return x
+
+
+def chain_tail(sd, T, B=256, forms=("auto",), data_seed=31337, seed=11, n_oracle=0, cache=True, log=print):
+    """-> {form: {"precision", "form", "probe", "vs3": stats over B windows, "vs3_first64", "ratio_to_probe", "per_window": tensor,
+    ["vs_oracle": [...], "three_vs_oracle": [...]]}}"""
+    data = make_motion_windows(B, T, seed=data_seed)
+    mask = head_condition_mask(data.shape)
+    g = torch.Generator().manual_seed(data_seed + 1)
+    x_T = torch.randn(data.shape, generator=g).cuda()
+    x_cond = (data * (1 - mask) + mask * torch.randn(data.shape, generator=g)).cuda()
+    m3 = build(sd, T, "3")
+    t0 = time.time()
+    want = philox_chain(m3, x_T, x_cond, seed)
+    log(f"  split-bf16 chain at B={B}: {time.time() - t0:.1f} s")
+    out = {}
+    models = {"3": m3}
+    for form in forms:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            t0 = time.time()
+            m = build(sd, T, form, cache)
+            m.hip_engine(verify=True)
+            t_pack = time.time() - t0
+            t0 = time.time()
+            got = philox_chain(m, x_T, x_cond, seed)
+            t_chain = time.time() - t0
+        models[form] = m
+        d = (got - want).abs().amax((1, 2)).cpu()
+        pr = m.hip_precision_probe or {}
+        name = f"{m.hip_precision_used} {pr.get('form') or 'as is'}"
+        pchain = (pr.get("errors") or {}).get(name + ", full chain")
+        r = {"precision": m.hip_precision_used, "form": pr.get("form"), "probe": pr.get("errors"), "probe_chain": pchain,
+             "probe_per_window": pr.get("chain_per_window"), "source": pr.get("source"),
+             "vs3": stats(d), "vs3_first64": stats(d[:64]), "per_window": d, "pack_s": t_pack, "chain_s": t_chain,
+             "ratio_to_probe": (float(d.max()) / pchain) if pchain else None, "warnings": [str(w.message)[:160] for w in rec]}
+        out[form] = r
+        log(f"  {form:5s} -> runs {name:22s} pack {t_pack:5.1f} s chain {t_chain:4.1f} s | B={B} vs split-bf16: max {r['vs3']['max']:.2e} "
+            f"p99 {r['vs3']['p99']:.2e} median {r['vs3']['median']:.2e} (first 64: max {r['vs3_first64']['max']:.2e}) | probe's whole chains "
+            f"({len(pr.get('chain_per_window') or [])} windows): {pchain if pchain is None else format(pchain, '.2e')} -> ratio "
+            f"{r['ratio_to_probe'] if r['ratio_to_probe'] is None else format(r['ratio_to_probe'], '.2f')}")
+        if rec:
+            log("        warnings: " + " | ".join(r["warnings"]))
+    if n_oracle:
+        from oracle import egoego_oracle as O  # (perf-debug tool: the oracle is the checker here, as in tests/)
+        n = n_oracle
+        gi = torch.Generator().manual_seed(data_seed + 2)
+        nz = {"x_T": torch.randn((n,) + tuple(data.shape[1:]), generator=gi), "cond": torch.randn((n,) + tuple(data.shape[1:]), generator=gi),
+              "steps": torch.randn((S, n) + tuple(data.shape[1:]), generator=gi)}
+        sched = O.make_schedule(S)
+        x = nz["x_T"].clone()
+        xc = data[:n] * (1 - mask[:n]) + mask[:n] * nz["cond"]
+        t0 = time.time()
+        with torch.no_grad():
+            for i, tv in enumerate(reversed(range(S))):
+                x = O.p_sample(sd, sched, x, torch.full((n,), tv, dtype=torch.long), xc, nz["steps"][i])
+        log(f"  fp32 oracle chain on {n} windows: {time.time() - t0:.0f} s of CPU ({torch.get_num_threads()} threads)")
+        for form, m in models.items():
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = m.sample(data[:n].cuda(), mask[:n].cuda(), noise=nz).cpu()
+            d = (got - x).abs().amax((1, 2))
+            (out[form] if form in out else out.setdefault("3", {}))["vs_oracle"] = [float(v) for v in d]
+            log(f"  {form:5s} vs the fp32 ORACLE, {n} windows, the oracle's draws: max {float(d.max()):.2e}  per window "
+                + " ".join(f"{float(v):.1e}" for v in d))
+    for m in models.values():
+        m.invalidate_engine()
+    return out
+
+
+def weights_for(kind, T):
+    if kind == "init":
+        return make_weights(ModelConfig(max_timesteps=T + 1), 0), {"kind": "initialisation (make_weights seed 0)"}
+    from make_trained_like_checkpoint import train_like
+    seed = int(kind.replace("seed", ""))
+    sd, info = train_like(3000, seed, "cuda", T)
+    return {k: v for k, v in sd.items() if k.startswith("denoise_fn.")}, info
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--weights", default="init,seed0,seed1,seed2")
+    ap.add_argument("--windows", default="120,196")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--forms", default="auto")
+    ap.add_argument("--oracle", type=int, default=0, help="windows against the fp32 CPU oracle (for the first --oracle-configs configurations)")
+    ap.add_argument("--oracle-configs", default="seed0:120")
+    ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    lines = []
+
+    def log(sx):
+        print(sx, flush=True)
+        lines.append(sx)
+    from egoego_release_amd import plan
+    log(f"# tools/chain_tail_b256.py --weights {args.weights} --windows {args.windows} --batch {args.batch} --forms {args.forms} --oracle {args.oracle}")
+    log(f"# limits in force: stage 1 {plan.PROBE_LIMIT:.1e}, whole chain {plan.CHAIN_LIMIT:.2e} on {plan.CHAIN_WINDOWS} probe windows; {torch.cuda.get_device_name(0)}")
+    ratios = []
+    for T in [int(v) for v in args.windows.split(",")]:
+        for kind in args.weights.split(","):
+            sd, info = weights_for(kind, T)
+            log(f"== weights {kind}, T={T}: {info}")
+            n_or = args.oracle if f"{kind}:{T}" in args.oracle_configs.split(",") else 0
+            res = chain_tail(sd, T, args.batch, args.forms.split(","), n_oracle=n_or, cache=not args.no_cache, log=log)
+            for form, r in res.items():
+                if r.get("ratio_to_probe"):
+                    ratios.append((kind, T, form, r["precision"], r["form"], r["vs3"]["max"], r["probe_chain"], r["ratio_to_probe"]))
+    log("== max over the batch / the probe's own whole-chain figure, per configuration")
+    for row in ratios:
+        log("   %-6s T=%-3d %-5s runs %s %-16s  B-max %.2e  probe %.2e  ratio %.2f" % row)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
