@@ -20,10 +20,29 @@ using AW8K = GemmCfg<2, 2, 4, 2, 1, 2, false, 2, 3>;
 using AW8V = GemmCfg<2, 2, 4, 2, 1, 2, true, 2, 3>;
 static_assert(AW8K::SMEM_BYTES == AL8K::SMEM_BYTES, "same ring as the 4-wave form");
 
+// EGOEGO_ATTN_PREFETCH (round 5): the Q projection's pipeline fill is requested BEFORE the K epilogue and the V projection's before S^T +
+// softmax (GemmBody::prefetch), so that two of the three fills' round trips run behind arithmetic instead of in front of a main loop.
+// For that the K / V^T image and the parameter block are STATIC LDS objects and only the operand ring is dynamic: hipcc puts a full
+// vmcnt(0) in front of any LDS access it cannot prove disjoint from a pending LDS-DMA destination, and distinct objects are what it can prove.
+// MEASURED (profiles/r05_attn_prefetch_ab.txt, B=256 and B=32, two runs each inside one gpurun): 199.2 / 199.6 us per launch with, 201.1 /
+// 197.5 without; steps 1.3805 / 1.3824 against 1.3821 / 1.3804 ms — nothing: with two waves per SIMD the fills were already covered.  Off
+// by default (round 4's layout); kept as an A/B knob of variant builds.
+#ifndef EGOEGO_ATTN_PREFETCH
+#define EGOEGO_ATTN_PREFETCH 0
+#endif
+static constexpr int AW_DYN_SMEM_BYTES = EGOEGO_ATTN_PREFETCH ? (int)GemmCfg<2, 2, 4, 2, 1, 2, false, 2, 3>::SMEM_BYTES : AL_SMEM_BYTES;
+
 __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if EGOEGO_ATTN_PREFETCH
+    __shared__ __attribute__((aligned(16))) char kv_img[AL_KV_BYTES];
+    __shared__ __attribute__((aligned(16))) float misc[AL_MISC_BYTES / 4];
+    char* kv = kv_img;                             // K image, later V^T image: [slice][tile][k32 block][1 KiB]
+    float* sk = misc;                              // [128] key row scales
+#else
     char* kv = smem;                               // K image, later V^T image: [slice][tile][k32 block][1 KiB]
     float* sk = (float*)(smem + AL_KV_BYTES);      // [128] key row scales
+#endif
     float* sv = sk + 128;                          // [256] V column scales
     float* red = sv + 256;                         // [512] cross-wave maxima
     float* p_ws = red + 512;                       // [3][256] weight row scales of Q_h, K_h, V_h
@@ -32,7 +51,14 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
     float* sqv = p_hs + 128;                       // [128] query row scales
     float* psum = sqv + 128;                       // [2][128] half-row sums of the probabilities (key half, query)
     static_assert((128 + 256 + 512 + 768 + 768 + 128 + 128 + 256) * 4 <= AL_MISC_BYTES, "parameter block");
+#if EGOEGO_ATTN_PREFETCH
+    char* ring = smem;                                // operand ring (the only dynamic LDS); between main loops: the Q image, then the P image
+#else
     char* ring = smem + AL_KV_BYTES + AL_MISC_BYTES;  // operand ring; between main loops: the Q image, then the P image
+#endif
+    using GK = GemmBody<AW8K, NoEpi>;
+    using GV = GemmBody<AW8V, NoEpi>;
+    constexpr bool PF = EGOEGO_ATTN_PREFETCH != 0;
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);  // the H heads of a window share an XCD (and its L2)
     const int bh = lid + a.bh0;
     const int b = bh / a.H, h = bh - b * a.H;
@@ -111,8 +137,9 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
     // ---- 1. K_h -> LDS ------------------------------------------------------------------------------
     {
         I8Acc q[2][2];
-        GemmBody<AW8K, NoEpi>::mainloop(g, a.H + h, b, ring, q, stage_params);
+        GK::mainloop(g, a.H + h, b, ring, q, stage_params);
         mark(1);
+        if (PF) GK::prefetch(g, h, b, ring);  // (the main loop ended with a barrier: the ring is idle)
         // (the 4-wave form adds the bias without a scale: x 1.0f is exact)
         rows_epilogue(q, 1, 1.0f, sk, kv);
     }
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
     float sq = 0.f;
     {
         I8Acc q[2][2];
-        GemmBody<AW8K, NoEpi>::mainloop(g, h, b, ring, q);  // (ends with a barrier: the ring is idle, every wave is past the K image writes)
+        GK::template mainloop<I8Acc, true, GK::NoPre, PF>(g, h, b, ring, q);  // (ends with a barrier: the ring is idle, every wave is past the K image writes)
         mark(3);
         rows_epilogue(q, 0, a.qscale, sqv, ring);
         __syncthreads();
@@ -134,6 +161,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
         }
         sq = sqv[(wave & 3) * 32 + col];
         __syncthreads();  // the Q image is in registers: the ring may be refilled (V projection)
+        if (PF) GV::prefetch(g, 2 * a.H + h, b, ring);
     }
     mark(4);
     // ---- 3. S^T = K Q^T, softmax over keys (TM:76-82): wave (query tile wave & 3, key half wave >> 2) -----------------------
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void attn_layer_i8w_kernel(AttnLayerArgs a)
     // ---- 4. V_h -> LDS (transposed, over the K image) ---------------------------------------------------
     {
         I8Acc q[2][2];
-        GemmBody<AW8V, NoEpi>::mainloop(g, 2 * a.H + h, b, ring, q);  // its first barrier: every wave is past S^T (the K image is dead)
+        GV::template mainloop<I8Acc, true, GV::NoPre, PF>(g, 2 * a.H + h, b, ring, q);  // its first barrier: every wave is past S^T (the K image is dead)
         mark(6);
         // the probabilities of the four query tiles -> LDS (over the idle ring) for the d_v-half waves of phase 5
 #pragma unroll

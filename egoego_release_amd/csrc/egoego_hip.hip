@@ -692,7 +692,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             }
             static DevOnce once;
             if (once.pending()) {
-                HIP_TRY(allow_smem(attn_layer_i8w_kernel, AL_SMEM_BYTES));
+                HIP_TRY(allow_smem(attn_layer_i8w_kernel, AW_DYN_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_layer_i8h_kernel, AL_SMEM_BYTES));
                 HIP_TRY(allow_smem(attn_proj_i8_kernel, ATTN_PROJ_SMEM));
                 HIP_TRY(allow_smem(attn_core_s_kernel, ATTN_CORE_S_SMEM));
@@ -727,7 +727,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                 attn_layer_i8h_kernel<<<dim3(nw * H * 2), dim3(512), AL_SMEM_BYTES, s>>>(al);
             } else {
                 c->last_kernel[EGOEGO_K_QKV] = "attn_layer_i8w_kernel";
-                attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AL_SMEM_BYTES, s>>>(al);
+                attn_layer_i8w_kernel<<<dim3(nw * H), dim3(512), AW_DYN_SMEM_BYTES, s>>>(al);
             }
             HIP_TRY(hipGetLastError());
         } else if (fused_attn) {

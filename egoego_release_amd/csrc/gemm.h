@@ -156,7 +156,44 @@ struct GemmBody {
     };
     // pre(): called once, after the pipeline-fill LDS-DMA of the prologue has been requested and before it is waited for — work with a
     // memory round trip of its own (a kernel's parameter staging) then shares the fill's instead of preceding it
-    template <class AccT, bool ZERO = true, class Pre = NoPre>
+    // prefetch(): the pipeline-fill requests of mainloop<..., PREFETCHED = true> on the same (g, fblk, tblk, smem), issued EARLY — by every
+    // wave, once the ring is idle (after the previous main loop's closing barrier) — so that the fill's round trip runs behind whatever
+    // the caller does in between (an epilogue that touches neither the ring nor global memory: the counted waits of the main loop assume
+    // that nothing else of this wave is in the vector-memory queue behind these requests).
+    static __device__ void prefetch(const GemmOperands& g, int fblk, int tblk, char* smem) {
+        constexpr int KS = C::KS, NP = C::NP, WT = C::WT, AT = C::AT, NW = C::NW, NCH = C::NCH, D = C::NSTAGE - 1;
+        const int wave = wave_id_uniform();
+        const int lane = threadIdx.x & 63;
+        const int ns = (g.kcount ? g.kcount : g.K16) / KS;
+        const u32x4* gp[NCH];
+        int dsto[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int blk = min(j * NW + wave, C::NBLK - 1);
+            dsto[j] = blk * 1024;
+            const int ks = blk % KS, t2 = blk / KS;
+            const u32x4* base;
+            if (t2 < WT * NP) {
+                const int p = t2 / WT, i = t2 % WT;
+                base = (const u32x4*)(g.w + (size_t)p * g.w_plane) + ((size_t)(fblk * WT + i) * g.K16 + ks) * 64;
+            } else {
+                const int t3 = t2 - WT * NP;
+                const int p = t3 / AT, i = t3 % AT;
+                base = (const u32x4*)(g.a + (size_t)p * g.a_plane) + ((size_t)(tblk * AT + i) * g.K16 + ks) * 64;
+            }
+            gp[j] = base + lane;
+        }
+        // (stage 0's requests before stage 1's: the main loop's first counted wait leaves exactly the newest stage in flight)
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < ns) {
+#pragma unroll
+                for (int j = 0; j < NCH; ++j)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (size_t)d * KS * 64),
+                                                     (__attribute__((address_space(3))) void*)(smem + (size_t)d * C::STAGE_BYTES + dsto[j]), 16, 0, 0);
+            }
+    }
+    template <class AccT, bool ZERO = true, class Pre = NoPre, bool PREFETCHED = false>
     static __device__ void mainloop(const GemmOperands& g, int fblk, int tblk, char* smem, AccT (&acc)[C::FT][C::TT], Pre pre = Pre{}) {
         constexpr int FT = C::FT, TT = C::TT, KS = C::KS, NP = C::NP, WT = C::WT, AT = C::AT, NW = C::NW;
         constexpr int NCH = C::NCH;
@@ -268,7 +305,7 @@ struct GemmBody {
         constexpr int DMA_PER_HALF = ((NCH + 2 * NMMA_HALF - 1) / (2 * NMMA_HALF)) * NMMA_HALF;
 #pragma unroll
         for (int d = 0; d < D; ++d)
-            if (d < ns && loads_on) {
+            if (d < ns && loads_on && !PREFETCHED) {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) issue_one(d, d, j);
             }

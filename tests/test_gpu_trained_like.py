@@ -335,3 +335,39 @@ def test_small_jobs_run_split_bf16_unprobed_and_the_verdict_is_cached(tmp_path, 
     m3._slot.unprobed_work = plan.PROBE_AFTER_WINDOW_STEPS
     m3.sample(xs.cuda(), cm.cuda())
     assert m3.hip_precision_used == _lib.PREC_I8X3_FC and m3.hip_precision_probe["source"] == "probe"
+
+
+def test_whole_chain_at_the_metrics_size_b256(trained):
+    """the WHOLE 1000-step chain at B = 256 (BASELINE configs[2]; its first 64 windows = configs[1]) in what `auto`
+    picks — for the initialisation and for the trained-like checkpoint — against split-bf16 with the same Philox draws, per window;
+    4 of the windows against the fp32 CPU oracle with the oracle's draws (tools/chain_tail_b256.py; all seeds, both window lengths
+    and every int8 form: profiles/r05_chain_tail_b256.txt).
+    A trained denoiser's chain amplifies ANY perturbation (tools/chain_sensitivity.py: x_T moved by 1e-6 — a few ulp — moves some
+    windows' split-bf16 result by more than the bar), so the bar is asserted on the windows whose split-bf16 chain is itself
+    reproducible (moves <= 1e-4 under that perturbation), and the others are counted and printed."""
+    from chain_tail_b256 import chain_tail
+    from chain_sensitivity import sensitivity
+    from egoego_release_amd import plan
+    BAR_VS_SPLIT = 8.5e-4  # + split-bf16's own ~1.2e-4 to the oracle at the end of 1000 steps (r05_chain_tail_b256.txt)
+    # ---- the initialisation: 9 as is, far inside
+    cfg = ModelConfig(max_timesteps=T + 1)
+    r = chain_tail(make_weights(cfg, 0), T, 256, ("auto",), log=lambda s: print(s))["auto"]
+    assert r["precision"] == _lib.PREC_I8X3_FC and r["form"] == "as is", r["probe"]
+    assert r["vs3"]["max"] <= BAR_VS_SPLIT and r["vs3"]["max"] <= 1.7 * r["probe_chain"], (r["vs3"], r["probe_chain"])
+    # ---- the trained-like checkpoint
+    sd, info = trained
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = chain_tail(sd, T, 256, ("auto",), n_oracle=4, log=lambda s: print(s))
+        sens = sensitivity(sd, T, 256, [1e-6], log=lambda s: print(s))["eps"][1e-6]
+    r = res["auto"]
+    stable = sens <= 1e-4
+    print(f"trained-like: auto runs {r['precision']} {r['form']}; windows whose split-bf16 chain moves > 1e-4 under a 1e-6 perturbation of x_T: "
+          f"{int((~stable).sum())} of 256 (largest move {float(sens.max()):.1e})")
+    assert int(stable.sum()) >= 230, "the trained-like checkpoint became too chaotic to say anything"
+    d = r["per_window"]
+    assert float(d[stable].max()) <= BAR_VS_SPLIT, (float(d[stable].max()), r["vs3"])
+    if r["probe_chain"]:  # (auto on an int8 form: what the plan's limit leaves room for — plan.CHAIN_LIMIT = BAR / 1.62, rounded down)
+        assert r["probe_chain"] <= plan.CHAIN_LIMIT and float(d[stable].max()) <= 1.75 * r["probe_chain"], (r["probe_chain"], float(d[stable].max()))
+    for form in ("auto", "3"):
+        assert max(res[form]["vs_oracle"]) < POSE_TOL, (form, res[form]["vs_oracle"])
