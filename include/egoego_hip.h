@@ -29,7 +29,9 @@
  *   - pose tensors are fp32, contiguous, [B][T][d_feats]; timesteps are int64 [B] (torch.long).
  *   - return value: 0 = ok; negative = error (EGOEGO_E_*); egoego_last_error() describes the last
  *     failure on the calling thread.
- *   - one context per device; a context is not thread-safe.  A context and each workspace are SINGLE-STREAM objects: the
+ *   - any number of contexts may live on one device (the Python side holds up to three at a time: the plan's, its unshifted
+ *     twin for padding-mask calls, and the split-bf16 reference of a pack-time measurement); a context is not thread-safe.
+ *     A context and each workspace are SINGLE-STREAM objects: the
  *     captured step graphs are shared by every call of a shape, and the per-workspace step state (timestep counters, the
  *     caller's buffer pointers, the Philox key) is rewritten by every loop call — two streams driving one workspace or one
  *     context concurrently race silently.  Use one context + workspace per stream.

@@ -38,9 +38,9 @@ def _ref_noise(shape, S, seed=123):
 
 def test_stagewise_against_oracle(prec):
     B, T, H = 2, 120, 4
-    # precision 9: the stops run the PRODUCT kernels and tap their int8 rows (one more 16-bit rounding per layer in fc, residuals rebuilt
-    # from int8 rows, and the tap itself is a row of 16-bit fixed point: values up to ~6 -> steps of 2e-4)
-    STAGE_TOL = 1e-3 if prec == _lib.PREC_I8X3_FC else globals()["STAGE_TOL"]
+    # precision 9: the stops run the PRODUCT kernels and tap their int8 rows: 16-bit FIXED point per row, so the error of a tap scales
+    # with its row's maximum (values up to ~5 -> steps of 1.5e-4).  Measured (tools/experiments/gain_cases.py, round 5): <= 2.2e-4 of the
+    # row maximum at every stop, 6.4e-4 absolute at the last layer's output; split-bf16: <= 5.4e-5 absolute.
     cfg, sd, m = _model(T, precision=prec)
     eng = m.hip_engine()
     x_all = torch.randn(B, T, 396, generator=torch.Generator().manual_seed(1120))
@@ -51,19 +51,27 @@ def test_stagewise_against_oracle(prec):
     xd, xcd, td = x_all[..., :198].contiguous().cuda(), x_all[..., 198:].contiguous().cuda(), t.cuda()
     L = T + 1
 
-    def err(got, want):
-        return (got.cpu() - want).abs().max().item()
+    seen = {}
 
-    assert err(eng.debug_stage(xd, xcd, td, 0, "embed"), taps["embed"]) < STAGE_TOL
+    def ok(got, want, name=None):
+        d = (got.cpu() - want).abs()
+        if prec == _lib.PREC_I8X3_FC:  # (the Q/K/V stops run split-bf16 projections, but on the product path's int8 layer input)
+            rel = float((d.amax(-1) / want.abs().amax(-1).clamp_min(1.0)).max())
+            seen[name] = (float(d.max()), rel)
+            return rel <= 3e-4 and float(d.max()) < 8e-4
+        return float(d.max()) < STAGE_TOL
+
+    assert ok(eng.debug_stage(xd, xcd, td, 0, "embed"), taps["embed"], "embed")
     for li in (0, 3):
         lt = taps[f"layer{li}"]
         hm = lambda a: a.view(H, B, L, 256).permute(1, 0, 2, 3)
         # Q/K/V taps: the i8x3 attention kernel keeps them on-chip, so these three stops run the split-bf16 projections
-        assert err(eng.debug_stage(xd, xcd, td, li, "q"), hm(lt["q"]) / 16.0) < STAGE_TOL
-        assert err(eng.debug_stage(xd, xcd, td, li, "k"), hm(lt["k"])) < STAGE_TOL
-        assert err(eng.debug_stage(xd, xcd, td, li, "v"), hm(lt["v"])) < STAGE_TOL
+        assert ok(eng.debug_stage(xd, xcd, td, li, "q"), hm(lt["q"]) / 16.0, f"{li}.q"), seen
+        assert ok(eng.debug_stage(xd, xcd, td, li, "k"), hm(lt["k"]), f"{li}.k"), seen
+        assert ok(eng.debug_stage(xd, xcd, td, li, "v"), hm(lt["v"]), f"{li}.v"), seen
         for st in ("attn_out", "attn_ln", "ffn_hidden", "out"):
-            assert err(eng.debug_stage(xd, xcd, td, li, st), lt[st]) < STAGE_TOL, (li, st)
+            assert ok(eng.debug_stage(xd, xcd, td, li, st), lt[st], f"{li}.{st}"), (li, st, seen)
+    print("stage taps (max abs, max relative to the row maximum):", {k: (f"{a:.1e}", f"{r:.1e}") for k, (a, r) in seen.items()})
 
 
 @pytest.mark.parametrize("T,tags", [(120, ("t0", "t500", "t999", "tmix")), (30, ("t0", "tmix")), (196, ("t0", "tmix"))])
@@ -100,6 +108,46 @@ def test_p_sample_golden(golden, objective, prec):
         y = m.p_sample(x_in, torch.full((2,), tval).cuda(), xc.cuda(), noise=noise.cuda())
         assert torch.equal(x_in.cpu(), x)  # like the reference, p_sample returns a new tensor
         assert np.abs(y.cpu().numpy() - golden[f"p_sample_{objective}_t{tval}"]).max() < POSE_TOL, (objective, tval)
+
+
+@pytest.mark.parametrize("objective", ["pred_x0", "pred_noise"])
+def test_surface_methods_against_oracle(objective):
+    """The reference's own decomposition of a step, method by method (M:216-246): `predict_start_from_noise`, `q_posterior` and
+    `p_mean_variance` (= denoiser on the HIP path + the two, with the in-place clamp) against the oracle's restatement of the same
+    lines, per-row timesteps included (the API takes a [B] tensor)."""
+    cfg, sd, m = _model(objective=objective)
+    sched = O.make_schedule(1000)
+    g = torch.Generator().manual_seed(41)
+    x, xc, eps = (torch.randn(3, 120, 198, generator=g) for _ in range(3))
+    t = torch.tensor([0, 417, 999])
+
+    def gat(name):
+        return sched[name].gather(-1, t).reshape(3, 1, 1)
+    # predict_start_from_noise (M:216-220) and q_posterior (M:222-229): schedule gathers + elementwise arithmetic
+    want_x0 = gat("sqrt_recip_alphas_cumprod") * x - gat("sqrt_recipm1_alphas_cumprod") * eps
+    got_x0 = m.predict_start_from_noise(x.cuda(), t.cuda(), eps.cuda()).cpu()
+    assert (got_x0 - want_x0).abs().max() <= 1e-6 * want_x0.abs().max()
+    x0 = torch.rand(3, 120, 198, generator=g) * 2 - 1
+    mean, var, logvar = m.q_posterior(x0.cuda(), x.cuda(), t.cuda())
+    want_mean = gat("posterior_mean_coef1") * x0 + gat("posterior_mean_coef2") * x
+    assert (mean.cpu() - want_mean).abs().max() <= 1e-6 * want_mean.abs().max()
+    assert torch.equal(var.cpu(), gat("posterior_variance")) and torch.equal(logvar.cpu(), gat("posterior_log_variance_clipped"))
+    assert var.shape == (3, 1, 1) and float(logvar[0]) == pytest.approx(-46.0517, abs=1e-3)  # (SURVEY Appendix A.0: clamp at 1e-20)
+    # p_mean_variance (M:231-246): the denoiser pass, the objective's x0, clamp_(-1, 1), q_posterior
+    with torch.no_grad():
+        out = O.denoise(sd, torch.cat((x, xc), -1), t)
+    w0 = out if objective == "pred_x0" else gat("sqrt_recip_alphas_cumprod") * x - gat("sqrt_recipm1_alphas_cumprod") * out
+    for clip in (True, False):
+        w = w0.clamp(-1.0, 1.0) if clip else w0
+        want_mean = gat("posterior_mean_coef1") * w + gat("posterior_mean_coef2") * x
+        mean, var, logvar = m.p_mean_variance(x.cuda(), t.cuda(), xc.cuda(), clip_denoised=clip)
+        # (pred_noise at t = 999 multiplies the denoiser's error by sqrt(1 / abar - 1) ~ 2e4 before the clamp bounds it: the clamped form is what sampling uses)
+        tol = POSE_TOL if (clip or objective == "pred_x0") else POSE_TOL * float(w0.abs().max())
+        assert (mean.cpu() - want_mean).abs().max() < tol, (objective, clip, float((mean.cpu() - want_mean).abs().max()))
+        assert torch.equal(var.cpu(), gat("posterior_variance")) and torch.equal(logvar.cpu(), gat("posterior_log_variance_clipped"))
+    with pytest.raises(ValueError, match="unknown objective"):
+        m.objective = "pred_v"
+        m.p_mean_variance(x.cuda(), t.cuda(), xc.cuda(), clip_denoised=True)
 
 
 def test_p_sample_default_noise_uses_torch_generator():
@@ -454,9 +502,10 @@ def test_outlier_heavy_layernorm_gains_step_the_default_precision_down():
     """One scale per row is 16-bit fixed point: LayerNorm gains far above the rest cost the other features their bits
     (DESIGN.md 3c).  `hip_precision = "auto"` (the default) MEASURES each checkpoint when it is packed (model._resolve_precision:
     int8 slices against split-bf16 on a probe batch): the reference's initialisation runs precision 9 with no warning; the SAME
-    six features amplified 25x in every LayerNorm (the worst case found, tools/gain_sweep.py) step down to split-bf16 — with
-    a warning — and the stepped-down result is inside the bar; mild gains stay on an int8 precision inside the bar; an explicit
-    int8 precision is kept and warned about."""
+    six features amplified 25x in every LayerNorm (the worst case found, tools/gain_sweep.py) — and already 3x — step down to
+    split-bf16, with a warning, and the stepped-down result is inside the bar; 2x runs precision 8 as is, silently, inside the bar
+    (every outcome below is what tools/experiments/gain_cases.py measured in round 5, pinned); an explicit int8 precision is kept and
+    warned about."""
     import warnings
     cfg = ModelConfig(max_timesteps=121)
     sd = make_weights(cfg, 0)
@@ -489,25 +538,39 @@ def test_outlier_heavy_layernorm_gains_step_the_default_precision_down():
         m = build(hot)
         got = m.denoise(xa, t.cuda(), xb).cpu()
     pr = m.hip_precision_probe
-    assert pr["errors"]["9 as is"] > pr["limit"]  # the plain int8 packing measures outside the limit on this checkpoint ...
-    if m.hip_precision_used == _lib.PREC_BF16X3:  # ... so either every int8 form was measured and split-bf16 runs, with a warning,
-        assert {"9 as is", "9 prepared", "9 prepared + fc24", "8 as is", "8 prepared"} <= set(pr["errors"])  # (+ ", full chain" entries of stage 2)
-        assert any("falling back to split-bf16" in str(w.message) for w in rec)
-    else:                                         # ... or a PREPARED int8 packing measured inside it (precision.py)
-        assert pr["prepared"] and not rec
-    # (these gains blow the outputs up to |y| ~ 25: the bar relative to that)
+    # every int8 form measures outside the limit on this checkpoint (round 5: 2.0 each — the rows' one scale is spent on six features):
+    # split-bf16 runs, with a warning
+    assert m.hip_precision_used == _lib.PREC_BF16X3 and any("falling back to split-bf16" in str(w.message) for w in rec)
+    assert {"9 as is", "9 prepared", "9 prepared + fc24", "8 as is", "8 prepared"} == set(pr["errors"]) and min(pr["errors"].values()) > pr["limit"]
+    # (these gains blow the outputs up to |y| ~ 50: the bar relative to that)
     assert (got - want).abs().max().item() < POSE_TOL * max(1.0, want.abs().max().item())
+    # gains of 3x: the same outcome (measured: the int8 forms 1.3e-3 ... 2.9e-3 on the probe), and the stepped-down result is inside the bar
+    warm = {k: v.clone() for k, v in sd.items()}
+    for k in warm:
+        if k.endswith("layer_norm.weight"):
+            warm[k][:6] *= 3.0
+    with torch.no_grad():
+        want = O.denoise(warm, x_all, t)
+    with pytest.warns(RuntimeWarning, match="falling back to split-bf16"):
+        m = build(warm)
+        got = m.denoise(xa, t.cuda(), xb).cpu()
+    assert m.hip_precision_used == _lib.PREC_BF16X3 and min(m.hip_precision_probe["errors"].values()) > m.hip_precision_probe["limit"]
+    assert (got - want).abs().max().item() < POSE_TOL
+    # gains of 2x: precision 9 fails both packings (1.2e-3 / 7.7e-4 / 8.2e-4), precision 8 as is measures 4.5e-4 and 4.6e-4 on the whole
+    # chains: it runs, without a warning, ~40 % slower than 9, inside the bar
     mild = {k: v.clone() for k, v in sd.items()}
     for k in mild:
         if k.endswith("layer_norm.weight"):
-            mild[k][:6] *= 2.0  # an int8 precision measures inside the limit: no warning, inside the bar
+            mild[k][:6] *= 2.0
     with torch.no_grad():
         want = O.denoise(mild, x_all, t)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         m = build(mild)
         got = m.denoise(xa, t.cuda(), xb).cpu()
-    assert m.hip_precision_used in (_lib.PREC_I8X3_FC, _lib.PREC_I8X3)
+    pr = m.hip_precision_probe
+    assert m.hip_precision_used == _lib.PREC_I8X3 and pr["form"] == "as is", pr
+    assert pr["errors"]["9 as is"] > pr["limit"] and pr["errors"]["8 as is"] <= pr["limit"] and pr["errors"]["8 as is, full chain"] <= pr["chain_limit"]
     assert (got - want).abs().max().item() < POSE_TOL * max(1.0, want.abs().max().item())
     with pytest.warns(RuntimeWarning, match="differs from split-bf16"):  # an explicit int8 precision, packed as is, is kept and warned about
         m = build(hot, _lib.PREC_I8X3_FC)
