@@ -446,7 +446,9 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
                     }
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f, pmax = 0.f;
+            // row sum in the order of the eight-wave form (attn_core_i8w.h): tiles 0..3, then the rest, each half summed across the two
+            // half-waves first — so that the two forms give the same bits
+            float sum2[2] = {0.f, 0.f}, pmax = 0.f;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -457,12 +459,14 @@ __global__ __launch_bounds__(256, 1) void attn_core_i8_kernel(AttnCore8Args a) {
                     for (int c = 0; c < 4; ++c) {
                         const int r = 4 * gq + c;
                         const float e = __builtin_amdgcn_exp2f(p[kt][r] - mx);
-                        sum += e;
+                        sum2[kt >= 4] += e;
                         p[kt][r] = e * vs[c];  // the key's V scale rides on the probability
                         pmax = fmaxf(pmax, p[kt][r]);
                     }
                 }
-            sum += __shfl_xor(sum, 32);
+            sum2[0] += __shfl_xor(sum2[0], 32);
+            sum2[1] += __shfl_xor(sum2[1], 32);
+            const float sum = sum2[0] + sum2[1];
             pmax = fmaxf(pmax, __shfl_xor(pmax, 32));
             // q = rint(p * pk) <= P_QMAX for every p <= pmax: the quarter unit of slack covers the rounding of pk and of the product
             const float pk = pmax > 1e-30f ? (P_QMAX - 0.25f) / pmax : 0.f;  // (below: every V row of the window is zero to fp32 — O is 0)

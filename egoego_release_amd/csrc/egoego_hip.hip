@@ -17,6 +17,7 @@
 #include "attn_layer_i8h.h"
 #include "attn_split_i8.h"
 #include "attn_core_i8.h"
+#include "attn_core_i8w.h"
 #include "common.h"
 #include "gemm.h"
 #include "pointwise.h"
@@ -592,10 +593,35 @@ static int launch_attn_core8_kt(AttnCore8Args a, int BH, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return 0;
 }
+// the eight-wave form (attn_core_i8w.h, round 5); EGOEGO_CORE4=1 (variant builds) keeps the four-wave form for A/B runs
+#ifndef EGOEGO_CORE4
+#define EGOEGO_CORE4 0
+#endif
+template <int KT, bool O8>
+static int launch_attn_core8w_kt(AttnCore8Args a, int BH, hipStream_t s) {
+    auto kern = attn_core_i8w_kernel<KT, O8>;
+    constexpr int smem = attn_core8w_smem_bytes<KT>();
+    static DevOnce once;
+    static int n_cu[64];  // compute units per device: the persistent grid (one workgroup per CU)
+    if (once.pending()) {
+        HIP_TRY(allow_smem(kern, smem));
+        int cu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, once.dev));
+        n_cu[once.dev & 63] = cu;
+        once.done();
+    }
+    const int dev = once.dev;
+    a.BH = BH;
+    const int items = BH * ((KT + 3) / 4);
+    kern<<<dim3(std::min(items, std::max(1, n_cu[dev & 63]))), dim3(512), smem, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 static int launch_attn_core8(const AttnCore8Args& a, int KT, int BH, hipStream_t s) {
     // (only windows of 129..224 tokens take this path: seven key tiles; shorter ones run the one-kernel layer or the split-bf16 core)
     if (KT != 7) return fail(EGOEGO_E_INVALID, "unsupported key-tile count %d", KT);
-    return a.o8 ? launch_attn_core8_kt<7, true>(a, BH, s) : launch_attn_core8_kt<7, false>(a, BH, s);
+    if (EGOEGO_CORE4) return a.o8 ? launch_attn_core8_kt<7, true>(a, BH, s) : launch_attn_core8_kt<7, false>(a, BH, s);
+    return a.o8 ? launch_attn_core8w_kt<7, true>(a, BH, s) : launch_attn_core8w_kt<7, false>(a, BH, s);
 }
 
 // ------------------------------------------------------------------------------------ the step
