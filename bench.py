@@ -339,7 +339,7 @@ def main():
             "attn_layer_i8h_kernel": "the one-kernel int8 attention layer as two half-query workgroups per window x head (small grids)",
             "attn_proj_i8_kernel": "Q/K/V projections of a window x head as three workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
             "attn_proj6_i8_kernel": "Q/K/V projections of a window x head as six workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
-            "qkv_i8q_kernel": "Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8_kernel; projection operations only",
+            "qkv_i8q_kernel": "Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8w_kernel; projection operations only",
             "qkv_i8_kernel": "Q/K/V projections on int8 slices for the split-bf16 attention core; projection operations only",
             "qkv_attn_kernel": "fused Q/K/V projection + attention, split-bf16",
             "qkv_kernel": "Q/K/V projections, split-bf16; projection operations only"}

@@ -13,6 +13,9 @@
 //     work on the same half and the buffers turn over as before: V^T half 0 streams in during the second d_k half of S^T, half 1 behind the
 //     probabilities' hand-over, the NEXT item's K halves as the V^T halves are spent (persistent workgroups, attn_core_i8.h);
 //   * int8 output: the row maximum of the head's 256 features crosses the pair through LDS.
+// Measured and NOT kept (round 5, one gpurun each): the logits as I * (s_k 256 log2 e) with the query's scale applied inside the exponent's fma —
+// one multiply and one subtraction less per probability — 149.7 us per launch against 147.0: the softmax phase (5.5 of an item's 18 us) does
+// not follow the instruction count; a wave-uniform branch per key tile for the key mask instead of a select per value: no change.
 // What one wave's VALU phases and LDS waits cost, the other wave's MFMAs now cover.  Same integers as the four-wave form; the row sum of the
 // probabilities is the sum of the pair's two partial sums (tiles 0..3, then the rest).
 #pragma once

@@ -805,7 +805,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
                     if (fc8) {
                         ca.o8 = w.O8; ca.o8_plane = w.o_plane; ca.o_scale = w.O_scale;
                     }
-                    c->last_kernel[EGOEGO_K_ATTN] = "attn_core_i8_kernel";
+                    c->last_kernel[EGOEGO_K_ATTN] = EGOEGO_CORE4 ? "attn_core_i8_kernel" : "attn_core_i8w_kernel";
                     if (int r = launch_attn_core8(ca, g.KT, g.B * H, s)) return r;
                 }
             } else if (i8 && !dbg_qkv) {

@@ -153,7 +153,7 @@ def test_trained_like_forward_and_chain_against_oracle(trained):
 
 
 def test_trained_like_long_window_against_oracle():
-    """The same at BASELINE configs[3]'s window (T = 196: `qkv_i8q_kernel` + `attn_core_i8_kernel<7>`, V scaled per key, the
+    """The same at BASELINE configs[3]'s window (T = 196: `qkv_i8q_kernel` + `attn_core_i8w_kernel<7>`, V scaled per key, the
     probabilities' scale per query): a checkpoint trained at that length, what `auto` picks for it, one forward and a 50-step
     chain against the oracle.  (Round 4: with two-slice probabilities in the long-window core `auto`'s pick ended this chain
     8.7e-4 from split-bf16 although its probe said 3.5e-4; with three slices 3.6e-4 / 1.7e-4.)"""

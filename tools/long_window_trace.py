@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timelines of the long-window pair (T = 196: qkv_i8q_kernel + attn_core_i8_kernel<7>), perf-debug build:
+"""Phase timelines of the long-window pair (T = 196: qkv_i8q_kernel + attn_core_i8w_kernel<7>, or attn_core_i8_kernel<7> in an EGOEGO_CORE4 build), perf-debug build:
 per-workgroup wall-clock stamps at the phase boundaries.   python -m egoego_release_amd.build --perfdebug first."""
 import ctypes as C
 import os
@@ -54,4 +54,4 @@ c = raw[90112 + 131072:90112 + 131072 + B * 4 * 2 * 8].view(-1, 8)
 c = c[c[:, 5] > 0]
 cyc = (c[:, 7] - c[:, 6]).double()
 print("S^T phase: %.0f shader cycles per workgroup = %.0f MHz; 168 MFMAs per wave -> %.1f cycles per MFMA issued" % (cyc.mean(), (cyc / ((c[:, 2] - c[:, 1]).double() / 100.0)).mean(), cyc.mean() / 168))
-report("attn_core_i8_kernel<7>", c[:, :6], ("K half 0 + Q landed", "S^T (both halves)", "softmax + quantise P", "PV, both d_v halves", "row maxima + int8 store"))
+report("attention core (7 key tiles)", c[:, :6], ("K half 0 + Q landed", "S^T (both halves)", "softmax + quantise P", "PV, both d_v halves", "row maxima + int8 store"))
