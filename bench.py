@@ -309,7 +309,7 @@ def main():
 
     traffic, traffic_src = {}, None
     try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command, summarised under profiles/
-        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(tp):
                 continue

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Copy a round's judged summaries from gpurun_out/$R (scratch) into profiles/ (tracked).  Run in the authoring container
 # after `gpurun -- bash tools/profile_round.sh`.
-R=${EGOEGO_ROUND:-r04}
+R=${EGOEGO_ROUND:-r05}
 O=gpurun_out/$R
 set -e
-for f in bench_b256_t120 bench_b32_t120 bench_b64_t120 bench_b128_t120 bench_b256_t196 bench_2ranks_gloo_one_gpu bench_1rank_rccl_forced_gather bench_b256_t120_trained_like bench_b256_t120_trained_like_p3; do
+for f in bench_b256_t120 bench_b32_t120 bench_b64_t120 bench_b128_t120 bench_b256_t196 bench_2ranks_gloo_one_gpu bench_1rank_rccl_forced_gather bench_b256_t120_trained_like bench_b256_t120_trained_like_p3 bench_b256_t196_trained_like bench_b64_t120_trained_like; do
   grep -h "^{" $O/$f.json | tail -1 > profiles/${R}_$f.json
 done
 cp $O/step_times.jsonl profiles/${R}_step_times.jsonl

@@ -5,7 +5,7 @@
 #   2. per-kernel time summaries                         rocprofv3 --kernel-trace --stats  (same commands, fewer steps)
 #   3. PMC counters, three separate passes               rocprofv3 --kernel-trace --pmc ...   (no --sys-trace etc.)
 # (the rocprofv3 runs pass --precision 9 — what "auto" picks for the synthetic weights — so that the probe of "auto" does not mix its small-batch launches into the per-kernel averages)
-R=${EGOEGO_ROUND:-r04}
+R=${EGOEGO_ROUND:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
@@ -16,6 +16,8 @@ EGOEGO_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 100 --warmup 10 --no-
 EGOEGO_FORCE_COLLECTIVE=1 python3 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_1rank_rccl_forced_gather.json 2>> $O/bench.err
 python3 bench.py --steps 200 --warmup 10 --weights trained-like --no-cpu-baseline > $O/bench_b256_t120_trained_like.json 2>> $O/bench.err
 python3 bench.py --steps 200 --warmup 10 --weights trained-like --precision 3 --no-cpu-baseline > $O/bench_b256_t120_trained_like_p3.json 2>> $O/bench.err
+python3 bench.py --steps 100 --warmup 10 --window 196 --weights trained-like --no-cpu-baseline > $O/bench_b256_t196_trained_like.json 2>> $O/bench.err
+python3 bench.py --steps 200 --warmup 10 --batch 64 --weights trained-like --no-cpu-baseline > $O/bench_b64_t120_trained_like.json 2>> $O/bench.err
 python3 tools/step_times.py --steps 100 --batches 1,16,24,32,64,128,256 --windows 120,196 --api > $O/step_times.jsonl 2>> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 bench.py --steps 20 --warmup 3 --precision 9 --no-probe --no-cpu-baseline > $O/stats.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b32 -o stats -- python3 bench.py --steps 50 --warmup 3 --batch 32 --precision 9 --no-probe --no-cpu-baseline > $O/stats_b32.log 2>&1

@@ -29,7 +29,7 @@ ATTN_CORE_FLOPS = B * 4 * L * L * HD  # QK^T + PV alone: north_star's "attention
 def main():
     """Everything below is recomputed from the files under profiles/ (kernel stats of the un-profiled-clock run, the PMC summary with
     its own per-pass durations, the traffic json): no number comes from prose."""
-    rnd = os.environ.get("EGOEGO_ROUND", "r04")
+    rnd = os.environ.get("EGOEGO_ROUND", "r05")
     stats = list(csv.DictReader(open(os.path.join(ROOT, "profiles", rnd + "_bench_b256_t120_kernel_stats.csv"))))
     traffic = json.load(open(os.path.join(ROOT, "profiles", rnd + "_traffic.json")))["kernels"]
     pmc = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", rnd + "_pmc_per_kernel.csv")))}

@@ -36,7 +36,7 @@ def main():
             continue
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         out["kernels"][k] = {"fetch_kb_raw": f, "write_kb": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    with open(os.path.join(ROOT, "profiles", os.environ.get("EGOEGO_ROUND", "r04") + "_traffic.json"), "w") as fh:
+    with open(os.path.join(ROOT, "profiles", os.environ.get("EGOEGO_ROUND", "r05") + "_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     for k, v in out["kernels"].items():
         print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch")
