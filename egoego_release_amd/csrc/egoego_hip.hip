@@ -330,11 +330,31 @@ __global__ __launch_bounds__(C::NT, C::MINW) void layer_tail_i8_kernel(GemmOpera
     __syncthreads();
     if (stop == 2) return;
     {
+        // The integer sums are dequantised IN PLACE, tile by tile (an fp32 value takes its int32's register), and the LayerNorm epilogue reads
+        // the same storage as floats: a separate fp32 tile next to the integer one is 2 x 128 registers of a 256-register wave (round 4:
+        // 83 spilled registers, 264 bytes of scratch — and a launch slower than the all-split-bf16 tail's).
         I8One q[C::FT][C::TT];
         i8_gemm(g_2, q);
-        f32x16 acc[C::FT][C::TT];
-        i8_dequant_tile<true>(q, acc, par + 1024, e_1.q8_scale, f0, t0, lane);
-        e_2.template run<C::FT, C::TT>(acc, f0, t0, lane, wf, wt, smem);
+        {
+            const int hf = lane >> 5, col = lane & 31;
+            float sa[C::TT];
+#pragma unroll
+            for (int j = 0; j < C::TT; ++j) sa[j] = e_1.q8_scale[t0 + j * 32 + col];
+#pragma unroll
+            for (int i = 0; i < C::FT; ++i) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < C::TT; ++j) {
+                    f32x16 o;
+                    i8_dequant(q[i][j], o, par + 1024 + f0 + i * 32 + 4 * hf, sa[j]);
+                    q[i][j].v = __builtin_bit_cast(i32x16, o);
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        e_2.template run<C::FT, C::TT>(reinterpret_cast<f32x16(&)[C::FT][C::TT]>(q), f0, t0, lane, wf, wt, smem);
     }
 }
 // the int8 FFN passes of the 512f x 64t, 4-wave tile: pass 1 stages the high slices of two k-blocks per ring stage, pass 2 both
