@@ -9,9 +9,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegoego_hip.so")
 PERFDEBUG_LIB_PATH = os.path.join(os.path.dirname(_PKG), "tools", "_build", "libegoego_hip_perfdebug.so")  # tools/ only: `build --perfdebug`
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_NO_GRAPH = 1
 FLAG_FC24 = 2  # precision 9 only: fc's weights as three int8 slices (include/egoego_hip.h)
+FLAG_FFN16 = 4  # precision 8 only: the FFN contractions on split-bf16 (int8 slices in the attention layer only)
 PRED_NOISE, PRED_X0 = 0, 1
 NOISE_INJECTED, NOISE_PHILOX, NOISE_NONE = 0, 1, 2
 PREC_BF16X3, PREC_BF16X1, PREC_I8X3, PREC_I8X3_FC = 3, 1, 8, 9

@@ -717,7 +717,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
         // the fused kernel has one workgroup per (window, head): below ~one workgroup per CU the unfused pair
         // (12 projection blocks per window) spreads the same work over more CUs
         const bool i8 = NP == 2 && prec_i8(c);
-        const bool ffn8 = i8;  // i8x3: the FFN contractions run on int8 slices too (every batch size: same integers, same bits)
+        const bool ffn8 = i8 && !(c->cfg.flags & EGOEGO_FLAG_FFN16);  // i8x3: the FFN contractions run on int8 slices too (every batch size: same integers, same bits) unless EGOEGO_FLAG_FFN16 keeps them on split-bf16
         // EGOEGO_PREC_I8X3_FC: fc as well, where the attention kernel can hand O over as int8 rows (the two int8 attention back
         // ends: windows of more than 64 tokens); the Q/K/V debug stops run the split-bf16 projections and never reach fc
         const bool fc8 = i8 && c->cfg.precision == EGOEGO_PREC_I8X3_FC && (g.KT == 4 || g.KT == 7);
@@ -1120,7 +1120,9 @@ int egoego_ctx_create(const egoego_config* cfg, int device, egoego_ctx** out) {
     if (cfg->precision != EGOEGO_PREC_BF16X3 && cfg->precision != EGOEGO_PREC_BF16X1 && cfg->precision != EGOEGO_PREC_I8X3 &&
         cfg->precision != EGOEGO_PREC_I8X3_FC)
         return fail(EGOEGO_E_INVALID, "unknown precision %d", cfg->precision);
-    if (cfg->flags & ~(EGOEGO_FLAG_NO_GRAPH | EGOEGO_FLAG_FC24)) return fail(EGOEGO_E_INVALID, "unknown flags 0x%x", cfg->flags);
+    if (cfg->flags & ~(EGOEGO_FLAG_NO_GRAPH | EGOEGO_FLAG_FC24 | EGOEGO_FLAG_FFN16)) return fail(EGOEGO_E_INVALID, "unknown flags 0x%x", cfg->flags);
+    if ((cfg->flags & EGOEGO_FLAG_FFN16) && cfg->precision != EGOEGO_PREC_I8X3)
+        return fail(EGOEGO_E_INVALID, "EGOEGO_FLAG_FFN16 needs precision %d", EGOEGO_PREC_I8X3);
     if ((cfg->flags & EGOEGO_FLAG_FC24) && cfg->precision != EGOEGO_PREC_I8X3_FC)
         return fail(EGOEGO_E_INVALID, "EGOEGO_FLAG_FC24 needs precision %d", EGOEGO_PREC_I8X3_FC);
     int ndev = 0;
@@ -1697,7 +1699,7 @@ int egoego_debug_stage(egoego_ctx* c, const float* d_x, const float* d_xc, const
                 k_unpack_tiled<<<2048, 256, 0, s>>>(w.hB, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);
             break;
         case EGOEGO_DBG_FFN_HIDDEN:
-            if (prec_i8(c))  // the hidden activations exist as int8 rows only
+            if (prec_i8(c) && !(c->cfg.flags & EGOEGO_FLAG_FFN16))  // the hidden activations exist as int8 rows only
                 k_unpack_rows_i8<<<2048, 256, 0, s>>>(w.F8, w.h_plane, w.F_scale, N_MODEL, g.Lp, L, B, d_out, 1);
             else
                 k_unpack_tiled<<<2048, 256, 0, s>>>(w.F, w.h_plane, N_MODEL, g.Lp, L, B, d_out, lo);

@@ -209,7 +209,7 @@ class CondGaussianDiffusion(nn.Module):
         # a step — the fastest; 8 (PREC_I8X3) = fc, linear_out and the residuals on split-bf16; 3 (PREC_BF16X3) = split-bf16
         # everywhere (~2e-5 on one forward on every checkpoint measured, ~85 % more time per step than 9).  The int8 precisions are
         # 16-bit FIXED point per row: what they lose depends on the checkpoint, so "auto" (default) is decided by MEASUREMENT and
-        # remembered (plan.py): the ladder 9 as is -> 9 prepared -> 9 prepared + fc24 -> 8 as is -> 8 prepared -> 3, each candidate
+        # remembered (plan.py): the ladder 9 as is -> 9 prepared -> 9 prepared + fc24 -> 8 as is -> 8 prepared -> 8 prepared + ffn16 -> 3, each candidate
         # against split-bf16 on a probe batch (stage 1: the end of a chain + two forwards; stage 2: whole chains on 32 windows);
         # the verdict is cached on disk per checkpoint; a chain-level call shorter than the probe runs split-bf16 unprobed; under
         # torch.distributed the sharded entry points (dist.py) make all ranks pack rank 0's plan.  `hip_precision_used` /
@@ -223,6 +223,7 @@ class CondGaussianDiffusion(nn.Module):
         self.hip_probe_at_pack = True     # False: no measurement at all (auto = 9, absolute envelope for the runtime guard)
         self.hip_probe_full_chain = True  # False: 'auto' trusts stage 1 of the probe (saves ~1 s per measured checkpoint at 1000 steps)
         self.hip_fc24 = True              # 'auto' may run precision 9 with fc's weights as three int8 slices (FLAG_FC24, ~+10 % per step) before falling back to 8
+        self.hip_ffn16 = True             # 'auto' may run precision 8 with the FFN on split-bf16 (FLAG_FFN16: int8 slices in the attention layer only) before falling back to 3
         self.hip_int8_prep = "auto"       # pack-time preparation of int8 precisions (precision.py): "auto" = only when the plain packing fails the probe; "always"; "never"
         self.hip_plan_cache = True        # remember / reuse the verdict on disk ($EGOEGO_HIP_CACHE, default ~/.cache/egoego_hip; plan.py)
         self.hip_plan_override = None     # tools/tests: (precision, prepared, flags) — pack exactly this form (measured and reported, never rejected)
@@ -248,7 +249,7 @@ class CondGaussianDiffusion(nn.Module):
         `_weights_fingerprint()` at chain-level entry points and by the `invalidate_engine()` hooks."""
         dev = self.betas.device
         return (str(dev), self.hip_precision, bool(self.hip_graph), self.objective, int(self.betas.shape[0]),
-                self.hip_int8_prep, bool(self.hip_probe_at_pack), bool(self.hip_probe_full_chain), bool(self.hip_fc24),
+                self.hip_int8_prep, bool(self.hip_probe_at_pack), bool(self.hip_probe_full_chain), bool(self.hip_fc24), bool(self.hip_ffn16),
                 None if self.hip_plan_override is None else tuple(self.hip_plan_override), bool(self.hip_plan_cache),
                 tuple((p.data_ptr(), p._version) for p in self._packed_tensors()))
 

@@ -2,10 +2,11 @@
 disk, and agreed on by all ranks of a process group.
 
     resolve(model, job)         the ladder of model.hip_precision = "auto" (and the check of an explicit int8 precision):
-                                  9 as is -> 9 prepared -> 9 prepared + fc24 -> 8 as is -> 8 prepared -> 3 (RuntimeWarning)
+                                  9 as is -> 9 prepared -> 9 prepared + fc24 -> 8 as is -> 8 prepared -> 8 prepared + ffn16 -> 3 (RuntimeWarning)
                                 stage 1 per candidate (precision.PrecisionProbe.error: the end of a chain + two forwards against
                                 split-bf16, PROBE_LIMIT), stage 2 for the candidate that passed (the WHOLE num_timesteps chain from
-                                noise on CHAIN_WINDOWS windows against split-bf16, CHAIN_LIMIT).
+                                noise on CHAIN_WINDOWS windows against split-bf16: CHAIN_LIMIT, and AMPLIFICATION_LIMIT for what the chain makes
+                                of one forward's error — a chain that amplifies operand rounding runs split-bf16 whatever the packing).
     cache                       the verdict (and the prepared weights) keyed by the weights' checksum, the module's shape and knobs,
                                 the limits and the library's own hash, under $EGOEGO_HIP_CACHE (default ~/.cache/egoego_hip):
                                 a second process packs the same checkpoint without measuring again.
@@ -33,18 +34,26 @@ from .precision import PrecisionProbe, prepare_int8_state, _engine_cfg
 PROBE_LIMIT = 5e-4       # stage 1 (cheap, every candidate): largest difference from split-bf16 on the end of a chain + two forwards:
                          # half the 1e-3 bar — a short chain on other data ran 1.5-1.7x its probe figure (trained-like checkpoint)
 PROBE_TAIL = 50          # ancestral steps of stage 1's end-of-chain run
-CHAIN_WINDOWS = 32       # stage 2: windows of the whole-chain probe (round 4 used the 4 stage-1 windows; the error is heavy-tailed over windows)
-CHAIN_LIMIT = 5.2e-4     # stage 2: the worst of CHAIN_WINDOWS whole chains against split-bf16.  DERIVED (round 5, profiles/r05_chain_tail_b256.txt): the
-                         # bar is 1e-3 against the fp32 reference; split-bf16 itself ends whole chains <= 1.24e-4 from the fp32 oracle (16 windows),
-                         # which leaves 8.5e-4 against split-bf16 for the worst window of a B = 256 batch; over 3 trained-like checkpoints x 2 window
-                         # lengths x 4 int8 forms + the initialisation, that worst window sat at 0.86-1.62x this probe's figure for the same
-                         # packing (1.03-1.11x on the initialisation): 8.5e-4 / 1.62 = 5.25e-4, rounded down
+CHAIN_WINDOWS = 128      # stage 2: windows of the whole-chain probe, conditions shaped like the reference's use (precision.PrecisionProbe).  Round 4
+                         # used 4 windows, round 5 first 32: two draws of 32 windows read the SAME packing 4.95e-4 and 7.06e-4, and one draw
+                         # accepted a checkpoint whose real batch holds a window 9.9e-3 away (profiles/r05_chain_tail_probe128_*.txt)
+CHAIN_LIMIT = 6.0e-4     # stage 2: the worst of CHAIN_WINDOWS whole chains against split-bf16.  DERIVED (round 5, profiles/r05_chain_tail_*.txt): the bar is
+                         # 1e-3 against the fp32 reference; split-bf16 itself ends whole chains <= 1.24e-4 from the fp32 oracle (16 windows), which
+                         # leaves 8.5e-4 against split-bf16 for the worst window of a B = 256 batch; that worst window sat at <= 1.40x the 128-window
+                         # probe's figure for the same packing wherever no amplifying window was involved (1.00-1.21x on the initialisation):
+                         # 8.5e-4 / 1.40 = 6.07e-4, rounded down
+AMPLIFICATION_LIMIT = 3.0  # stage 2: the whole chain's worst window over ONE forward's error of the same packing.  The reference's initialisation: ~1.0 (a
+                         # chain ends where its last forward ends).  Trained-like checkpoints: 5-10 — their chains ACCUMULATE operand rounding,
+                         # heavy-tailed over windows: in 2 of 6 (checkpoint, window length) pairs a batch or probe of 128-256 windows held a window
+                         # whose last 50 steps multiply any difference along one direction by ~11 and end 1e-2 away in EVERY int8 form
+                         # (tools/experiments/outlier_window.py), while the other windows sat at 5-8e-4 — no sample of windows bounds that tail.  So a
+                         # 16-bit fixed-point form is accepted only for a checkpoint whose chain does not amplify it; otherwise "auto" is split-bf16
 SMALL_JOB_WINDOW_STEPS = 16 * 1000       # "auto", chain-level calls: below this many window-steps the job is shorter than the probe
 PROBE_AFTER_WINDOW_STEPS = 8 * 16 * 1000  # ... until this much work has been done unprobed by one module
 
 
 def form_name(prepared, flags):
-    return ("prepared" if prepared else "as is") + (" + fc24" if flags & _lib.FLAG_FC24 else "")
+    return ("prepared" if prepared else "as is") + (" + fc24" if flags & _lib.FLAG_FC24 else "") + (" + ffn16" if flags & _lib.FLAG_FFN16 else "")
 
 
 def plain_plan(precision, source, probe=None):
@@ -69,6 +78,8 @@ def ladder(model):
             out.append((p, True, 0))
         if want == "auto" and p == _lib.PREC_I8X3_FC and prep == "auto" and model.hip_fc24:
             out.append((p, True, _lib.FLAG_FC24))
+        if want == "auto" and p == _lib.PREC_I8X3 and prep == "auto" and model.hip_ffn16:
+            out.append((p, True, _lib.FLAG_FFN16))
     return out
 
 
@@ -84,7 +95,7 @@ def run_ladder(model):
     explicit = want != "auto" or model.hip_plan_override is not None
     full_chain = model.hip_probe_full_chain and (want == "auto" or model.hip_plan_override is not None)
     probe = PrecisionProbe(model, tail=PROBE_TAIL, chain_windows=CHAIN_WINDOWS)
-    errors, calib, pick, best, rounded = {}, None, None, None, {}
+    errors, calib, pick, best, rounded, amplifies = {}, None, None, None, {}, None
     try:
         sd = probe.sd
         for prec, prepared, flags in ladder(model):
@@ -92,7 +103,8 @@ def run_ladder(model):
             if prepared:
                 calib = probe.calibration() if calib is None else calib
                 # (`rounded`: the compensated rounding of a weight depends on the weight and its calibration rows only — shared by every form)
-                sd_s, row_shift = prepare_int8_state(sd, calib, prec, shift=True, fc24=bool(flags & _lib.FLAG_FC24), cache=rounded)
+                sd_s, row_shift = prepare_int8_state(sd, calib, prec, shift=True, fc24=bool(flags & _lib.FLAG_FC24), ffn16=bool(flags & _lib.FLAG_FFN16),
+                                                       cache=rounded)
             else:
                 sd_s, row_shift = sd, None
             err, row_max = probe.error(sd_s, prec, row_shift, flags)
@@ -103,18 +115,30 @@ def run_ladder(model):
                 best = (err, cand)
             if err <= PROBE_LIMIT or model.hip_plan_override is not None:  # (an override is measured in full, whatever stage 1 says)
                 if full_chain:
+                    fwd = max(probe.last_forward_error, 1e-7)
                     cerr, per_window = probe.chain_error(sd_s, prec, row_shift, flags)
                     errors[f"{prec} {fname}, full chain"] = cerr
+                    errors[f"{prec} {fname}, amplification"] = cerr / fwd
                     cand["chain_per_window"] = per_window
-                    if cerr > CHAIN_LIMIT and not explicit:
-                        continue
+                    if not explicit:
+                        if cerr / fwd > AMPLIFICATION_LIMIT:
+                            amplifies = (prec, fname, cerr / fwd)  # a property of the checkpoint's chain, not of this packing: no int8 form is tried further
+                            break
+                        if cerr > CHAIN_LIMIT:
+                            continue
                 pick = cand
                 break
     finally:
         probe.close()
     shown = ", ".join(f"precision {k}: {e:.1e}" for k, e in errors.items())
     warn = None
-    if pick is None and not explicit:
+    if pick is None and not explicit and amplifies is not None:
+        plan = plain_plan(_lib.PREC_BF16X3, "probe")
+        warn = (f"hip_precision='auto': this checkpoint's sampling chain amplifies operand rounding {amplifies[2]:.1f}x (precision {amplifies[0]} {amplifies[1]}: the worst of "
+                f"{CHAIN_WINDOWS} whole chains over one forward's error; limit {AMPLIFICATION_LIMIT:.0f}x) — on such a chain single windows of a large batch end "
+                f"10x further from the reference than the rest in every 16-bit fixed-point form (DESIGN.md 3c), so split-bf16 (3) runs, ~85 % more time per "
+                f"step; measured: {shown}.  An explicit hip_precision = 8 / 9 overrides this")
+    elif pick is None and not explicit:
         plan = plain_plan(_lib.PREC_BF16X3, "probe")
         warn = (f"hip_precision='auto': the int8-slice precisions differ from split-bf16 by more than {PROBE_LIMIT:.0e} (end of a chain, "
                 f"forwards) / {CHAIN_LIMIT:.1e} (whole chain) on the probe batch for this checkpoint ({shown}); falling back to split-bf16 "
@@ -126,7 +150,7 @@ def run_ladder(model):
     else:
         plan = dict(pick, source="probe")
     chosen = pick if pick is not None else (best[1] if explicit else None)
-    plan["probe"] = {"errors": errors, "limit": PROBE_LIMIT, "chain_limit": CHAIN_LIMIT, "chain_windows": CHAIN_WINDOWS,
+    plan["probe"] = {"errors": errors, "limit": PROBE_LIMIT, "chain_limit": CHAIN_LIMIT, "chain_windows": CHAIN_WINDOWS, "amplification_limit": AMPLIFICATION_LIMIT,
                      "row_max": chosen["envelope"] if chosen else None, "prepared": bool(chosen and chosen["prepared"]),
                      "form": chosen["form"] if chosen else None,
                      "chain_per_window": chosen.get("chain_per_window") if chosen else None}
@@ -161,9 +185,9 @@ def cache_key(model, fingerprint):
     """Everything a verdict depends on: the weights (checksum), the module's shape, the knobs that shape the ladder, the limits,
     the device kind and the library itself."""
     what = [_lib.ABI_VERSION, _lib_hash(), [repr(v) for v in fingerprint], sorted(_engine_cfg(model).items()), str(model.hip_precision),
-            model.hip_int8_prep, bool(model.hip_fc24), bool(model.hip_probe_full_chain),
+            model.hip_int8_prep, bool(model.hip_fc24), bool(model.hip_ffn16), bool(model.hip_probe_full_chain),
             list(model.hip_plan_override) if model.hip_plan_override is not None else None,
-            PROBE_LIMIT, PROBE_TAIL, CHAIN_WINDOWS, CHAIN_LIMIT,
+            PROBE_LIMIT, PROBE_TAIL, CHAIN_WINDOWS, CHAIN_LIMIT, AMPLIFICATION_LIMIT,
             torch.cuda.get_device_name(model.betas.device) if model.betas.device.type == "cuda" else str(model.betas.device)]
     return hashlib.sha256(json.dumps(what, sort_keys=True, default=str).encode()).hexdigest()[:32]
 

@@ -79,12 +79,24 @@ class PrecisionProbe:
             gc = torch.Generator().manual_seed(self.SEED + 2)
             self.xT_chain = torch.randn((chain_windows, T, D), generator=gc).to(dev)
             self.xc_chain = torch.randn((chain_windows, T, D), generator=gc).to(dev)
+            if D == 198:
+                # conditions shaped like the reference's own use (trainer:210-221, M:264-265): the head joint's position and rotation of a
+                # motion — one the model itself generates (10 DDIM steps in split-bf16 under the random conditions above) — and noise on every
+                # other dimension.  A chain driven by pure-noise conditions is out of the model's distribution and amplifies more (round 5:
+                # the probe then over-predicts a trained-like checkpoint's real tail by up to 1.6x and under-predicts it by as much).
+                from .synthetic import head_condition_mask
+                gen = self.xT_chain.clone()
+                ts = sorted({int(round(v)) for v in np.linspace(0, S - 1, min(10, S))}, reverse=True)
+                self.ref.ddim_loop_(gen, self.xc_chain, ts)
+                mask = head_condition_mask(gen.shape, device=dev)
+                self.xc_chain = (gen * (1.0 - mask) + mask * self.xc_chain).contiguous()
         self._want_chain = None
         if S > 2 and probe is None:
             self.cases.append((S // 2, self._renoise(S // 2)))
         self.n_tail = min(tail, S)
         self.x_tail = self._renoise(self.n_tail - 1)
         self._want = None
+        self.last_forward_error = 0.0
 
     def _renoise(self, tv):
         t = torch.full((self.Bp,), tv, device=self.dev, dtype=torch.long)
@@ -123,6 +135,7 @@ class PrecisionProbe:
                 t = torch.full((self.Bp,), tv, device=self.dev, dtype=torch.long)
                 raw = eng.denoise(x, self.xc, t)
                 err = max(err, float((self._x0(raw, x, t) - w0).abs().max()), float((raw - wraw).abs().max()) / wmax)
+            self.last_forward_error = err  # (one pass: what plan.py's amplification figure divides a whole chain's error by)
             err = max(err, float((self._tail_chain(eng) - tail).abs().max()))
             return err, eng.outlier_stats(self.Bp, self.T)
         finally:
@@ -226,7 +239,7 @@ def compensated_rounding(W, X, damp=0.01, block=128):
 
 
 @torch.no_grad()
-def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=False, fc24=False, cache=None):
+def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=False, fc24=False, cache=None, ffn16=False):
     """The state dict an int8-slice engine of precision `prec` is packed from: mean-shifted LayerNorm rows (folded into biases and
     LayerNorm shifts), K / V minus their mean rows, and compensated rounding of the weights that precision contracts on int8
     slices.  Returns (state dict, row_shift) where row_shift = {'embed' | (layer, 'attn_ln' | 'out' | 'k' | 'v' | 'attn_out'): m} are
@@ -242,6 +255,8 @@ def prepare_int8_state(sd, calib, prec, shift=True, rounding=True, shift_kv=Fals
     int8_w = {"qkv", "w_1", "w_2"} | ({"fc", "linear_out"} if prec == _lib.PREC_I8X3_FC else set())
     if fc24:  # FLAG_FC24: the library takes THREE slices of fc's weights — they keep their fp32 values
         int8_w.discard("fc")
+    if ffn16:  # FLAG_FFN16: the FFN contractions run on split-bf16 — their weights keep their fp32 values
+        int8_w -= {"w_1", "w_2"}
     names = {"qkv": ("self_attn.w_q", "self_attn.w_k", "self_attn.w_v"), "fc": ("self_attn.fc",), "w_1": ("pos_ffn.w_1",), "w_2": ("pos_ffn.w_2",)}
     # ---- weights: compensated rounding on the grid the library will pack them onto
     W = {}

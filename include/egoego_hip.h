@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define EGOEGO_ABI_VERSION 5 /* 5: EGOEGO_FLAG_FC24 */
+#define EGOEGO_ABI_VERSION 6 /* 5: EGOEGO_FLAG_FC24; 6: EGOEGO_FLAG_FFN16 */
 
 enum {
     EGOEGO_OK = 0,
@@ -96,6 +96,11 @@ enum { EGOEGO_FLAG_NO_GRAPH = 1 };
  * 16-bit grid is what separates precision 9 from 8 at the end of a 1000-step chain; the Python layer's "auto"
  * tries this form before falling back to precision 8.  Hand the fc weights over UNROUNDED when it is set. */
 enum { EGOEGO_FLAG_FC24 = 2 };
+/* EGOEGO_PREC_I8X3 only: the FFN contractions (pos_ffn.w_1 / w_2, TM:102-103) on split-bf16 like fc — int8 slices are then confined to
+ * the attention layer (Q/K/V projections, QK^T, PV).  Fewer fixed-point sites at the time per step of precision 8 on large batches (its
+ * int8-FFN tail is no faster than the split-bf16 one there); the Python layer's "auto" tries this form after "8 prepared".
+ * Hand the FFN weights over UNROUNDED when it is set. */
+enum { EGOEGO_FLAG_FFN16 = 4 };
 
 /* fp32 device tensors in the reference checkpoint layout, contiguous. */
 typedef struct {

@@ -39,6 +39,7 @@ def test_binding_constants_match_the_header():
     src = open(os.path.join(ROOT, "include", "egoego_hip.h")).read()
     enums = {k: int(v) for k, v in re.findall(r"\b(EGOEGO_[A-Z0-9_]+)\s*=\s*(\d+)", src)}
     assert enums["EGOEGO_FLAG_NO_GRAPH"] == _lib.FLAG_NO_GRAPH and enums["EGOEGO_FLAG_FC24"] == _lib.FLAG_FC24
+    assert enums["EGOEGO_FLAG_FFN16"] == _lib.FLAG_FFN16
     assert enums["EGOEGO_PREC_BF16X3"] == _lib.PREC_BF16X3 and enums["EGOEGO_PREC_I8X3"] == _lib.PREC_I8X3
     assert enums["EGOEGO_PREC_I8X3_FC"] == _lib.PREC_I8X3_FC
     assert int(re.search(r"#define EGOEGO_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION

@@ -281,8 +281,9 @@ def _plan_run(rank, world, out):
     res["second_prec"] = int(m.hip_precision_used)
     res["first"], res["second"] = first.cpu(), second.cpu()
     HipEngine.outlier_stats = real_stats
-    # ---- (b) a prepared plan travels from group rank 0 to the others, tensors included
-    cfg, sd = _hot_gain_weights()
+    # ---- (b) a prepared plan travels from group rank 0 to the others, tensors included (the massive-feature checkpoint: "9 as is" fails the
+    # probe on its LayerNorm-2 rows, a prepared packing — mean-shifted rows — passes)
+    cfg, sd = _massive_feature_weights()
     m2 = CondGaussianDiffusion(**cfg.ctor_kwargs())
     m2.load_state_dict(sd, strict=False)
     m2 = m2.cuda()

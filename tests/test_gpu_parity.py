@@ -440,6 +440,53 @@ def test_fc_weights_as_three_slices(T):
         HipEngine(ecfg, m.state_dict(), dev, _lib.PREC_I8X3, _lib.FLAG_FC24)
 
 
+@pytest.mark.parametrize("T", [120, 196])
+def test_ffn_on_split_bf16_in_precision_8(T):
+    """EGOEGO_FLAG_FFN16 (precision 8): the FFN contractions on split-bf16, int8 slices in the attention layer only.  The denoiser's error
+    against the oracle may only fall against plain precision 8 (two int8 sites fewer), the result differs from it (the flag is honoured), a
+    window has the same bits in a small call (the direct-operand tail) and in a large one (the fused 64-token tail), the stage taps of
+    the FFN read the split-bf16 tensors, and the flag is refused for any other precision."""
+    from egoego_release_amd.engine import HipEngine
+    from egoego_release_amd.precision import _engine_cfg
+    cfg, sd, m = _model(T=T, precision=_lib.PREC_I8X3)
+    ecfg = _engine_cfg(m)
+    dev = torch.device("cuda")
+    en = HipEngine(ecfg, m.state_dict(), dev, _lib.PREC_I8X3, _lib.FLAG_NO_GRAPH | _lib.FLAG_FFN16)
+    e8 = HipEngine(ecfg, m.state_dict(), dev, _lib.PREC_I8X3, _lib.FLAG_NO_GRAPH)
+    try:
+        g = torch.Generator().manual_seed(12)
+        B = 200
+        x = torch.randn(B, T, 198, generator=g)
+        xc = torch.randn(B, T, 198, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        taps = {}
+        with torch.no_grad():
+            want = O.denoise(sd, torch.cat((x[:2], xc[:2]), -1), t[:2], taps=taps)
+        big = en.denoise(x.cuda(), xc.cuda(), t.cuda())
+        sm = [v[:3].contiguous().cuda() for v in (x, xc, t)]
+        small = en.denoise(*sm)
+        plain = e8.denoise(*sm)
+        assert torch.equal(small, big[:3]) and not torch.equal(small, plain)
+        dn, d8 = small[:2].cpu() - want, plain[:2].cpu() - want
+        print(f"T={T}: max error ffn16 {float(dn.abs().max()):.2e} / precision 8 {float(d8.abs().max()):.2e}; rms {float(dn.pow(2).mean().sqrt()):.2e} / {float(d8.pow(2).mean().sqrt()):.2e}")
+        assert float(dn.abs().max()) < 3e-4 and float(dn.pow(2).mean().sqrt()) < 1.03 * float(d8.pow(2).mean().sqrt())
+        two = [v[:2].contiguous().cuda() for v in (x, xc, t)]
+        for st in ("attn_ln", "ffn_hidden", "out"):
+            got = en.debug_stage(two[0], two[1], two[2], 1, st).cpu()
+            assert float((got - taps["layer1"][st]).abs().max()) < 3e-4, st
+        y = x[:70].contiguous().cuda()
+        en.sample_loop_(y, xc[:70].contiguous().cuda(), 999, 4, noise_mode=_lib.NOISE_PHILOX, seed=5)
+        z = x[:3].contiguous().cuda()
+        en.sample_loop_(z, xc[:3].contiguous().cuda(), 999, 4, noise_mode=_lib.NOISE_PHILOX, seed=5)
+        assert torch.equal(z, y[:3])
+    finally:
+        en.close()
+        e8.close()
+    for bad in (_lib.PREC_I8X3_FC, _lib.PREC_BF16X3):
+        with pytest.raises(_lib.EgoEgoHipError):
+            HipEngine(ecfg, m.state_dict(), dev, bad, _lib.FLAG_FFN16)
+
+
 @pytest.mark.filterwarnings("ignore:LayerNorm gains span")  # (explicit int8 precisions on such a checkpoint: the module says so)
 @pytest.mark.parametrize("T", [120, 196, 48])
 def test_outlier_heavy_weights_stay_within_the_bar(prec, T):
@@ -541,7 +588,7 @@ def test_outlier_heavy_layernorm_gains_step_the_default_precision_down():
     # every int8 form measures outside the limit on this checkpoint (round 5: 2.0 each — the rows' one scale is spent on six features):
     # split-bf16 runs, with a warning
     assert m.hip_precision_used == _lib.PREC_BF16X3 and any("falling back to split-bf16" in str(w.message) for w in rec)
-    assert {"9 as is", "9 prepared", "9 prepared + fc24", "8 as is", "8 prepared"} == set(pr["errors"]) and min(pr["errors"].values()) > pr["limit"]
+    assert {"9 as is", "9 prepared", "9 prepared + fc24", "8 as is", "8 prepared", "8 prepared + ffn16"} == set(pr["errors"]) and min(pr["errors"].values()) > pr["limit"]
     # (these gains blow the outputs up to |y| ~ 50: the bar relative to that)
     assert (got - want).abs().max().item() < POSE_TOL * max(1.0, want.abs().max().item())
     # gains of 3x: the same outcome (measured: the int8 forms 1.3e-3 ... 2.9e-3 on the probe), and the stepped-down result is inside the bar

@@ -342,9 +342,8 @@ def test_whole_chain_at_the_metrics_size_b256(trained):
     picks — for the initialisation and for the trained-like checkpoint — against split-bf16 with the same Philox draws, per window;
     4 of the windows against the fp32 CPU oracle with the oracle's draws (tools/chain_tail_b256.py; all seeds, both window lengths
     and every int8 form: profiles/r05_chain_tail_b256.txt).
-    A trained denoiser's chain amplifies ANY perturbation (tools/chain_sensitivity.py: x_T moved by 1e-6 — a few ulp — moves some
-    windows' split-bf16 result by more than the bar), so the bar is asserted on the windows whose split-bf16 chain is itself
-    reproducible (moves <= 1e-4 under that perturbation), and the others are counted and printed."""
+    The initialisation's chain does not amplify operand rounding (whole chain / one forward ~1) and runs "9 as is" inside the bar on all 256
+    windows; the trained-like checkpoint's does (5-10x), and `auto` answers with split-bf16 (plan.AMPLIFICATION_LIMIT)."""
     from chain_tail_b256 import chain_tail
     from chain_sensitivity import sensitivity
     from egoego_release_amd import plan
@@ -353,21 +352,26 @@ def test_whole_chain_at_the_metrics_size_b256(trained):
     cfg = ModelConfig(max_timesteps=T + 1)
     r = chain_tail(make_weights(cfg, 0), T, 256, ("auto",), log=lambda s: print(s))["auto"]
     assert r["precision"] == _lib.PREC_I8X3_FC and r["form"] == "as is", r["probe"]
-    assert r["vs3"]["max"] <= BAR_VS_SPLIT and r["vs3"]["max"] <= 1.7 * r["probe_chain"], (r["vs3"], r["probe_chain"])
-    # ---- the trained-like checkpoint
+    assert r["vs3"]["max"] <= BAR_VS_SPLIT and r["vs3"]["max"] <= 1.5 * r["probe_chain"], (r["vs3"], r["probe_chain"])
+    assert r["probe"]["9 as is, amplification"] <= plan.AMPLIFICATION_LIMIT  # (its chain ends where its last forward ends: ~1.0)
+    # ---- the trained-like checkpoint: its chain AMPLIFIES operand rounding (whole chain / one forward > 3), so `auto` is split-bf16 — with
+    # a warning that says so — and the int8 form that measures best is reported next to it
     sd, info = trained
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        res = chain_tail(sd, T, 256, ("auto",), n_oracle=4, log=lambda s: print(s))
+        res = chain_tail(sd, T, 256, ("auto", "8pn"), n_oracle=4, log=lambda s: print(s))
         sens = sensitivity(sd, T, 256, [1e-6], log=lambda s: print(s))["eps"][1e-6]
     r = res["auto"]
-    stable = sens <= 1e-4
-    print(f"trained-like: auto runs {r['precision']} {r['form']}; windows whose split-bf16 chain moves > 1e-4 under a 1e-6 perturbation of x_T: "
-          f"{int((~stable).sum())} of 256 (largest move {float(sens.max()):.1e})")
-    assert int(stable.sum()) >= 230, "the trained-like checkpoint became too chaotic to say anything"
-    d = r["per_window"]
-    assert float(d[stable].max()) <= BAR_VS_SPLIT, (float(d[stable].max()), r["vs3"])
-    if r["probe_chain"]:  # (auto on an int8 form: what the plan's limit leaves room for — plan.CHAIN_LIMIT = BAR / 1.62, rounded down)
-        assert r["probe_chain"] <= plan.CHAIN_LIMIT and float(d[stable].max()) <= 1.75 * r["probe_chain"], (r["probe_chain"], float(d[stable].max()))
+    amp = {k: v for k, v in r["probe"].items() if k.endswith("amplification")}
+    print(f"trained-like: auto runs {r['precision']} ({r['warnings'][:1]}); amplification {amp}; largest move of a split-bf16 chain under a 1e-6 "
+          f"perturbation of x_T: {float(sens.max()):.1e}")
+    assert r["precision"] == _lib.PREC_BF16X3 and amp and max(amp.values()) > plan.AMPLIFICATION_LIMIT, r["probe"]
+    assert any("amplifies operand rounding" in w for w in r["warnings"]), r["warnings"]
+    assert float(sens.max()) <= 1e-4  # ... and it is not chaos: the split-bf16 chain itself is reproducible on every window
+    # the best int8 form on the same batch (what an explicit hip_precision would run): typical windows sit inside the bar, which is all a
+    # sample can say about a chain that amplifies (2 of 6 such checkpoints held a window 1e-2 away)
+    n8 = res["8pn"]
+    print(f"trained-like, 8 prepared + ffn16 (not what auto runs): worst of 256 windows {n8['vs3']['max']:.2e}, p99 {n8['vs3']['p99']:.2e}")
+    assert n8["vs3"]["p99"] <= BAR_VS_SPLIT
     for form in ("auto", "3"):
         assert max(res[form]["vs_oracle"]) < POSE_TOL, (form, res[form]["vs_oracle"])

@@ -20,9 +20,9 @@ def _model():
 
 def test_ladder_order_and_knobs():
     m = _model()
-    F = _lib.FLAG_FC24
-    assert plan.ladder(m) == [(9, False, 0), (9, True, 0), (9, True, F), (8, False, 0), (8, True, 0)]
-    m.hip_fc24 = False
+    F, N = _lib.FLAG_FC24, _lib.FLAG_FFN16
+    assert plan.ladder(m) == [(9, False, 0), (9, True, 0), (9, True, F), (8, False, 0), (8, True, 0), (8, True, N)]
+    m.hip_fc24 = m.hip_ffn16 = False
     assert plan.ladder(m) == [(9, False, 0), (9, True, 0), (8, False, 0), (8, True, 0)]
     m.hip_int8_prep = "never"
     assert plan.ladder(m) == [(9, False, 0), (8, False, 0)]
@@ -30,7 +30,7 @@ def test_ladder_order_and_knobs():
     assert plan.ladder(m) == [(8, True, 0)]
     m.hip_plan_override = (9, True, F)
     assert plan.ladder(m) == [(9, True, F)]
-    assert plan.form_name(True, F) == "prepared + fc24" and plan.form_name(False, 0) == "as is"
+    assert plan.form_name(True, F) == "prepared + fc24" and plan.form_name(False, 0) == "as is" and plan.form_name(True, N) == "prepared + ffn16"
 
 
 def test_small_job_rule():

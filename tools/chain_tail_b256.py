@@ -24,7 +24,7 @@ from egoego_release_amd import ModelConfig, make_weights, head_condition_mask, _
 from egoego_release_amd.model import CondGaussianDiffusion  # noqa: E402
 from egoego_release_amd.synthetic import make_motion_windows  # noqa: E402
 
-FORMS = {"auto": None, "9": (9, False, 0), "9p": (9, True, 0), "9pf": (9, True, _lib.FLAG_FC24), "8": (8, False, 0), "8p": (8, True, 0)}
+FORMS = {"auto": None, "9": (9, False, 0), "9p": (9, True, 0), "9pf": (9, True, _lib.FLAG_FC24), "8": (8, False, 0), "8p": (8, True, 0), "8pn": (8, True, _lib.FLAG_FFN16)}
 S = 1000
 
 
@@ -92,6 +92,9 @@ def chain_tail(sd, T, B=256, forms=("auto",), data_seed=31337, seed=11, n_oracle
             f"p99 {r['vs3']['p99']:.2e} median {r['vs3']['median']:.2e} (first 64: max {r['vs3_first64']['max']:.2e}) | probe's whole chains "
             f"({len(pr.get('chain_per_window') or [])} windows): {pchain if pchain is None else format(pchain, '.2e')} -> ratio "
             f"{r['ratio_to_probe'] if r['ratio_to_probe'] is None else format(r['ratio_to_probe'], '.2f')}")
+        pw = pr.get("chain_per_window") or []
+        if len(pw) > 32:
+            log("        the probe's maximum over its first n windows: " + ", ".join(f"{n}: {max(pw[:n]):.2e} (x{float(d.max()) / max(pw[:n]):.2f})" for n in (32, 64, 128, 256) if n <= len(pw)))
         if rec:
             log("        warnings: " + " | ".join(r["warnings"]))
     if n_oracle:
@@ -139,6 +142,8 @@ def main():
     ap.add_argument("--oracle", type=int, default=0, help="windows against the fp32 CPU oracle (for the first --oracle-configs configurations)")
     ap.add_argument("--oracle-configs", default="seed0:120")
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--probe-windows", type=int, default=0, help="run the plan's whole-chain probe on this many windows (default: plan.CHAIN_WINDOWS) and also print its "
+                                                                 "maximum over the first 32 / 64 / ... of them: what a probe of that size would have said")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     lines = []
@@ -147,6 +152,8 @@ def main():
         print(sx, flush=True)
         lines.append(sx)
     from egoego_release_amd import plan
+    if args.probe_windows:
+        plan.CHAIN_WINDOWS = args.probe_windows
     log(f"# tools/chain_tail_b256.py --weights {args.weights} --windows {args.windows} --batch {args.batch} --forms {args.forms} --oracle {args.oracle}")
     log(f"# limits in force: stage 1 {plan.PROBE_LIMIT:.1e}, whole chain {plan.CHAIN_LIMIT:.2e} on {plan.CHAIN_WINDOWS} probe windows; {torch.cuda.get_device_name(0)}")
     ratios = []
