@@ -139,3 +139,81 @@ def test_eight_gloo_ranks_even_and_ragged(tmp_path):
         noise = {"x_T": torch.randn(B, 5, 9, generator=g), "cond": torch.randn(B, 5, 9, generator=g)}
         assert torch.equal(torch.load(out), _fake_sampler(xs, cm, noise, 0))
     assert [D.shard_bounds(250, r, 8) for r in range(8)][:3] == [(0, 32), (32, 64), (64, 95)]
+
+
+# ------------------------------------------------------------------------------------------ the ladder's decisions, with a scripted probe
+class _ScriptedProbe:
+    """Stand-in for precision.PrecisionProbe: errors per (precision, form) come from a table (no GPU)."""
+    table = {}
+
+    def __init__(self, model, tail=0, chain_windows=0):
+        self.sd = {"w": torch.zeros(2)}
+        self.last_forward_error = 0.0
+        self.calls = []
+
+    def calibration(self):
+        return {"rows": {}, "n_layers": 0}
+
+    def error(self, sd, prec, row_shift=None, flags=0):
+        stage1, fwd, _ = self.table[(prec, sd.get("form", "as is"))]
+        self.last_forward_error = fwd
+        return stage1, [4.0] * 8
+
+    def chain_error(self, sd, prec, row_shift=None, flags=0):
+        chain = self.table[(prec, sd.get("form", "as is"))][2]
+        return chain, [chain] * 4
+
+    def close(self):
+        pass
+
+
+def _scripted(monkeypatch, table):
+    _ScriptedProbe.table = table
+    monkeypatch.setattr(plan, "PrecisionProbe", _ScriptedProbe)
+
+    def fake_prepare(sd, calib, prec, shift=True, fc24=False, ffn16=False, cache=None, **kw):
+        return {"w": torch.ones(2), "form": plan.form_name(True, (_lib.FLAG_FC24 if fc24 else 0) | (_lib.FLAG_FFN16 if ffn16 else 0))}, {"embed": torch.zeros(1)}
+    monkeypatch.setattr(plan, "prepare_int8_state", fake_prepare)
+
+
+def test_ladder_decisions_with_a_scripted_probe(monkeypatch):
+    """run_ladder on tables of (stage-1 error, one forward's error, worst whole chain) per packing: which form is picked, what stops the
+    ladder, which warning is issued — the decisions of DESIGN.md 3c without a GPU."""
+    L, C, A = plan.PROBE_LIMIT, plan.CHAIN_LIMIT, plan.AMPLIFICATION_LIMIT
+    m = _model()
+    # 1. the initialisation's pattern: "9 as is" inside every limit, the chain ends where its last forward ends
+    _scripted(monkeypatch, {(9, "as is"): (3.3e-4, 3.2e-4, 3.5e-4)})
+    p = plan.run_ladder(m)
+    assert (p["precision"], p["form"], p["warn"]) == (9, "as is", None) and p["sd"] is None
+    assert p["probe"]["errors"]["9 as is, amplification"] == 3.5e-4 / 3.2e-4 and p["envelope"] == [4.0] * 8
+    # 2. a trained-like pattern: as is fails stage 1, prepared passes it, but the chain makes 7.8x of one forward's error: split-bf16, and
+    #    no further int8 form is even tried
+    _scripted(monkeypatch, {(9, "as is"): (7.4e-4, 6e-4, 0), (9, "prepared"): (1.5e-4, 1.24e-4, 9.7e-4)})
+    p = plan.run_ladder(m)
+    assert p["precision"] == 3 and "amplifies operand rounding 7.8x" in p["warn"] and set(p["probe"]["errors"]) == {
+        "9 as is", "9 prepared", "9 prepared, full chain", "9 prepared, amplification"}
+    # 3. the same forward errors on a chain that does NOT amplify but whose worst window is over the limit: the ladder walks on, and
+    #    precision 8 with the FFN on split-bf16 is the first form inside everything
+    tab = {(9, "as is"): (7e-4, 6e-4, 0), (9, "prepared"): (4e-4, 3.9e-4, C * 1.1), (9, "prepared + fc24"): (3.9e-4, 3.8e-4, C * 1.05),
+           (8, "as is"): (6e-4, 5e-4, 0), (8, "prepared"): (3.5e-4, 3.4e-4, C * 1.01), (8, "prepared + ffn16"): (3e-4, 2.9e-4, C * 0.9)}
+    _scripted(monkeypatch, tab)
+    p = plan.run_ladder(m)
+    assert (p["precision"], p["form"], p["flags"], p["warn"]) == (8, "prepared + ffn16", _lib.FLAG_FFN16, None) and p["prepared"] and p["sd"] is not None
+    # 4. nothing passes stage 1: split-bf16 with the other warning, every form measured once
+    _scripted(monkeypatch, {k: (2 * L, 2 * L, 0) for k in tab})
+    p = plan.run_ladder(m)
+    assert p["precision"] == 3 and "falling back to split-bf16" in p["warn"] and len(p["probe"]["errors"]) == 6
+    # 5. an explicit precision is kept — in the packing that measured best — and warned about; the amplification gate does not apply to it
+    m.hip_precision = 9
+    _scripted(monkeypatch, {(9, "as is"): (9e-4, 8e-4, 0), (9, "prepared"): (7e-4, 6e-4, 0)})
+    p = plan.run_ladder(m)
+    assert (p["precision"], p["form"]) == (9, "prepared") and "differs from split-bf16" in p["warn"]
+    _scripted(monkeypatch, {(9, "as is"): (2e-4, 1e-4, 1e-3)})
+    p = plan.run_ladder(m)
+    assert (p["precision"], p["form"], p["warn"]) == (9, "as is", None)
+    # 6. an override (tools) is measured in full, whatever the figures, and never rejected
+    m.hip_precision, m.hip_plan_override = "auto", (8, True, _lib.FLAG_FFN16)
+    _scripted(monkeypatch, {(8, "prepared + ffn16"): (9e-4, 1e-4, 2e-3)})
+    p = plan.run_ladder(m)
+    assert (p["precision"], p["form"]) == (8, "prepared + ffn16") and p["probe"]["errors"]["8 prepared + ffn16, amplification"] == 2e-3 / 1e-4
+    assert A == 3.0 and C == 6.0e-4 and plan.CHAIN_WINDOWS == 128  # (the figures DESIGN.md 3c derives)
