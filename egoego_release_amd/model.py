@@ -159,7 +159,7 @@ class _EngineSlot:
         self.envelope = None   # per LayerNorm site: the largest row maximum the pack-time probe has validated (runtime guard)
         self.demoted = False   # the runtime guard measured the int8 precision outside the limit on live inputs: "auto" now means 3
         self.force_repack = False  # ... and asked for the re-pack that applies it (a re-pack for any other reason clears `demoted`)
-        self.unprobed_work = 0     # window-steps sampled on a "small job" context (split-bf16, no probe): plan.is_small_job
+        self.unprobed_work = 0     # steps sampled on a "small job" context (split-bf16, no probe): plan.is_small_job
 
     def __deepcopy__(self, memo):
         return _EngineSlot()
@@ -361,7 +361,7 @@ class CondGaussianDiffusion(nn.Module):
     def _note_job(self, job):
         """A chain-level call ran on a context packed for a small job (split-bf16, unprobed): add its work up (plan.is_small_job)."""
         if self._slot.plan is not None and self._slot.plan["source"] == "small job":
-            self._slot.unprobed_work += job[0] * job[2]
+            self._slot.unprobed_work += job[2]
 
     @torch.no_grad()
     def _outlier_guard(self, eng, x, x_cond, group=None):

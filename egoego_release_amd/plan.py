@@ -13,7 +13,7 @@ disk, and agreed on by all ranks of a process group.
     small jobs                  a chain-level call that is SHORTER than the measurement (B x steps below SMALL_JOB_WINDOW_STEPS, no
                                 verdict cached) runs split-bf16 — always inside the bar, no probe, ~85 % more time per step on a job
                                 of a fraction of a second (the reference's own use: run_egoego.py:146, sample_bs = 1, two windows).
-                                The work done that way is added up; beyond PROBE_AFTER_WINDOW_STEPS the probe runs after all.
+                                The steps run that way are added up; beyond PROBE_AFTER_STEPS the probe runs after all.
     sync(model, ...)            under torch.distributed: ONE plan for all ranks.  Every rank reports whether its packed copy is
                                 stale (one all_reduce, always), and if any is, rank 0 resolves and broadcasts the plan — precision,
                                 form, flags AND the prepared tensors, so that every rank packs the same bits.
@@ -49,7 +49,9 @@ AMPLIFICATION_LIMIT = 3.0  # stage 2: the whole chain's worst window over ONE fo
                          # (tools/experiments/outlier_window.py), while the other windows sat at 5-8e-4 — no sample of windows bounds that tail.  So a
                          # 16-bit fixed-point form is accepted only for a checkpoint whose chain does not amplify it; otherwise "auto" is split-bf16
 SMALL_JOB_WINDOW_STEPS = 16 * 1000       # "auto", chain-level calls: below this many window-steps the job is shorter than the probe
-PROBE_AFTER_WINDOW_STEPS = 8 * 16 * 1000  # ... until this much work has been done unprobed by one module
+PROBE_AFTER_STEPS = 8 * 1000             # ... until one module has run this many STEPS unprobed: small jobs are launch-bound (0.43 ms per step in split-bf16
+                                         # against 0.23 in precision 9 whatever the batch, round 5), so each unprobed step loses ~0.2 ms and 8 chains of 1000 steps
+                                         # lose what the measurement costs (2-4 s)
 
 
 def form_name(prepared, flags):
@@ -236,7 +238,7 @@ def is_small_job(model, job):
     if job is None or model.hip_precision != "auto" or model.hip_plan_override is not None:
         return False
     b, _, steps = job
-    return b * steps < SMALL_JOB_WINDOW_STEPS and model._slot.unprobed_work < PROBE_AFTER_WINDOW_STEPS
+    return b * steps < SMALL_JOB_WINDOW_STEPS and model._slot.unprobed_work < PROBE_AFTER_STEPS
 
 
 def resolve(model, job=None, fingerprint=None):

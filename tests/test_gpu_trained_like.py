@@ -304,7 +304,7 @@ def test_small_jobs_run_split_bf16_unprobed_and_the_verdict_is_cached(tmp_path, 
         torch.manual_seed(5)  # (x_T and the condition noise come from torch's generator)
         a = m.sample(xs.cuda(), cm.cuda())
     assert m.hip_precision_used == _lib.PREC_BF16X3 and m.hip_precision_probe["source"] == "small job" and "skipped" in m.hip_precision_probe
-    assert m._slot.unprobed_work == 2 * 20
+    assert m._slot.unprobed_work == 20
     assert not os.path.isdir(tmp_path / "cache") or not os.listdir(tmp_path / "cache")  # nothing was measured: nothing to remember
     ref = _build(sd, _lib.PREC_BF16X3)
     ref.num_timesteps, ref.sampling_rng = 20, "philox"
@@ -327,12 +327,12 @@ def test_small_jobs_run_split_bf16_unprobed_and_the_verdict_is_cached(tmp_path, 
     assert m2.hip_precision_probe["errors"] == m.hip_precision_probe["errors"]
     print(f"pack + 20-step chain from a cached verdict: {dt:.2f} s")
     assert float((a - b).abs().max()) < 1e-3
-    # unprobed work adds up: beyond PROBE_AFTER_WINDOW_STEPS the next small job measures
+    # unprobed work adds up: beyond PROBE_AFTER_STEPS the next small job measures
     m3 = _build(make_weights(cfg, 8), hip_plan_cache=False)
     m3.num_timesteps, m3.sampling_rng = 20, "philox"
     m3.sample(xs.cuda(), cm.cuda())
     assert m3.hip_precision_used == _lib.PREC_BF16X3
-    m3._slot.unprobed_work = plan.PROBE_AFTER_WINDOW_STEPS
+    m3._slot.unprobed_work = plan.PROBE_AFTER_STEPS
     m3.sample(xs.cuda(), cm.cuda())
     assert m3.hip_precision_used == _lib.PREC_I8X3_FC and m3.hip_precision_probe["source"] == "probe"
 

@@ -38,7 +38,7 @@ def test_small_job_rule():
     assert plan.is_small_job(m, (2, 120, 1000))            # the reference's own use: two windows of one clip
     assert not plan.is_small_job(m, (256, 120, 1000)) and not plan.is_small_job(m, (64, 120, 1000)) and not plan.is_small_job(m, None)
     assert plan.is_small_job(m, (256, 120, 20))            # a 20-step slice of a big batch is short too
-    m._slot.unprobed_work = plan.PROBE_AFTER_WINDOW_STEPS  # ... until enough of them have run unprobed
+    m._slot.unprobed_work = plan.PROBE_AFTER_STEPS  # ... until enough of them have run unprobed
     assert not plan.is_small_job(m, (2, 120, 1000))
     m._slot.unprobed_work = 0
     m.hip_precision = 9                                    # an explicit precision is never replaced

@@ -11,6 +11,11 @@ cp $O/step_times.jsonl profiles/${R}_step_times.jsonl
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_b256_t120_kernel_stats.csv
 cp $(find $O/stats_b32 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_b32_t120_kernel_stats.csv
 cp $(find $O/stats_t196 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_b256_t196_kernel_stats.csv
+if [ -d $O/stats_p3 ]; then
+  cp $(find $O/stats_p3 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_b256_t120_p3_kernel_stats.csv
+  cp $(find $O/stats_p3_t196 -name "*kernel_stats.csv" | head -1) profiles/${R}_bench_b256_t196_p3_kernel_stats.csv
+  cp $O/step_times_p3.jsonl profiles/${R}_step_times_p3.jsonl
+fi
 A=$(find $O/pmc_a -name "*counter_collection.csv" | head -1); B=$(find $O/pmc_b -name "*counter_collection.csv" | head -1); C=$(find $O/pmc_c -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $A $B $C > profiles/${R}_pmc_per_kernel.csv
 python3 tools/fetch_calib.py $(find $O/calib_f -name "*counter_collection.csv" | head -1) $(find $O/calib_w -name "*counter_collection.csv" | head -1) > profiles/${R}_fetch_calibration.json

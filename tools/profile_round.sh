@@ -22,6 +22,10 @@ python3 tools/step_times.py --steps 100 --batches 1,16,24,32,64,128,256 --window
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 bench.py --steps 20 --warmup 3 --precision 9 --no-probe --no-cpu-baseline > $O/stats.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b32 -o stats -- python3 bench.py --steps 50 --warmup 3 --batch 32 --precision 9 --no-probe --no-cpu-baseline > $O/stats_b32.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_t196 -o stats -- python3 bench.py --steps 20 --warmup 3 --window 196 --precision 9 --no-probe --no-cpu-baseline > $O/stats_t196.log 2>&1
+# split-bf16 (what "auto" runs on a checkpoint whose chain amplifies operand rounding): per-kernel summaries and small-batch step times
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_p3 -o stats -- python3 bench.py --steps 20 --warmup 3 --precision 3 --no-probe --no-cpu-baseline > $O/stats_p3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_p3_t196 -o stats -- python3 bench.py --steps 20 --warmup 3 --window 196 --precision 3 --no-probe --no-cpu-baseline > $O/stats_p3_t196.log 2>&1
+python3 tools/step_times.py --steps 100 --batches 1,2,8,32 --windows 120,196 --precision 3 > $O/step_times_p3.jsonl 2>> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_a -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_a.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_b -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_b.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_c.log 2>&1
