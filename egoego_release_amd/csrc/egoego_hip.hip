@@ -463,17 +463,31 @@ static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
 }
 
 // Fused small-batch tail (tail_fused.h): 64-token workgroups when they fill the CUs exactly once, 32-token ones below.
+// EGOEGO_TAIL8_BF16=0 (variant builds): the split-bf16 tail of small grids on four 512-register waves, round 4's form
+#ifndef TAIL8_BF16
+#define TAIL8_BF16 1
+#endif
+#ifndef TAIL8_MAX_BLOCKS
+#define TAIL8_MAX_BLOCKS 256
+#endif
 template <bool FFN8>
 static int launch_tail_f(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_t s) {
     static DevOnce once;
     if (once.pending()) {
         HIP_TRY(allow_smem((tail_kernel<2, FFN8, false>), tail_smem_bytes(2)));
         HIP_TRY(allow_smem((tail_kernel<1, FFN8, false>), tail_smem_bytes(1)));
+        HIP_TRY(allow_smem((tail_kernel<1, false, false, false, 8>), tail_smem_bytes(1, 8)));
         once.done();
     }
     if (rows / 64 >= 256) {
         c->last_kernel[EGOEGO_K_FC_LN] = FFN8 ? "tail_kernel<2,true,false>" : "tail_kernel<2,false,false>";
         tail_kernel<2, FFN8, false><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
+    } else if (!FFN8 && TAIL8_BF16 && rows / 32 <= 160) {
+        // well under one workgroup per CU: the eight-wave build (two 256-register waves per SIMD, 64 features each), like the all-int8
+        // tail's — a workgroup is a serial chain there, and a SIMD's second wave issues its weight loads and MFMAs in the first one's waits
+        // (round 5, ms per step in split-bf16 at B = 1 / 8 / 32: 0.408 / 0.413 / 0.522 against 0.429 / 0.431 / 0.542 on four waves; a tie at 64 windows)
+        c->last_kernel[EGOEGO_K_FC_LN] = "tail_kernel<1,false,false,false,8>";
+        tail_kernel<1, false, false, false, 8><<<dim3(rows / 32), dim3(512), tail_smem_bytes(1, 8), s>>>(ta);
     } else {
         c->last_kernel[EGOEGO_K_FC_LN] = FFN8 ? "tail_kernel<1,true,false>" : "tail_kernel<1,false,false>";
         tail_kernel<1, FFN8, false><<<dim3(rows / 32), dim3(256), tail_smem_bytes(1), s>>>(ta);

@@ -383,9 +383,10 @@ template <int TT, bool FFN8, bool FC8 = false, bool W2 = false, int NWV = 4, boo
 __global__ __launch_bounds__(64 * NWV, ((W2 || NWV == 8) ? 2 : 1)) void tail_kernel(TailArgs a) {
     static_assert(!RES || (FFN8 && FC8 && TT == 1), "LDS-resident FFN operands: the all-int8 32-token tail");
     static_assert(!W2 || (FFN8 && FC8 && TT == 1), "the two-workgroups-per-CU build exists for the all-int8 32-token tail");
-    static_assert(NWV == 4 || (NWV == 8 && FFN8 && FC8 && TT == 1 && !W2), "the eight-wave build exists for the all-int8 32-token tail");
+    static_assert(NWV == 4 || (NWV == 8 && TT == 1 && !W2 && ((FFN8 && FC8) || (!FFN8 && !FC8 && !RES))),
+                  "the eight-wave build exists for the 32-token tails: all int8, or (round 5) all split-bf16");
     constexpr int TOK = 32 * TT, FT = 16 / NWV;
-    using G = DirectGemm<FT, TT, 4>;
+    using G = DirectGemm<FT, TT, 4, false, false, NWV>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const act = smem;
     char* const red = smem + G::SMEM_BYTES;  // the LayerNorm epilogues' cross-wave reduction scratch
