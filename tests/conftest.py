@@ -15,6 +15,12 @@ def pytest_configure(config):
     if "EGOEGO_HIP_CACHE" not in os.environ:
         import tempfile
         os.environ["EGOEGO_HIP_CACHE"] = tempfile.mkdtemp(prefix="egoego_hip_cache_")
+    # the fp32 CPU oracle runs chains of 1-8 windows: on the GPU box's 128+ hardware threads torch's default pool makes each small
+    # matmul SLOWER (a 1000-step chain of 4 windows: 195 s on 128 threads; the whole GPU suite 468 -> 236 s with 16); the oracle's results are compared within
+    # tolerances, never bit for bit with a thread count in between
+    import torch
+    if torch.get_num_threads() > 16:
+        torch.set_num_threads(16)
 
 
 @pytest.fixture(scope="session")

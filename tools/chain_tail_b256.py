@@ -107,10 +107,13 @@ def chain_tail(sd, T, B=256, forms=("auto",), data_seed=31337, seed=11, n_oracle
         x = nz["x_T"].clone()
         xc = data[:n] * (1 - mask[:n]) + mask[:n] * nz["cond"]
         t0 = time.time()
+        nt0 = torch.get_num_threads()
+        torch.set_num_threads(min(nt0, 16))  # a few windows on 128 threads run slower than on 16
         with torch.no_grad():
             for i, tv in enumerate(reversed(range(S))):
                 x = O.p_sample(sd, sched, x, torch.full((n,), tv, dtype=torch.long), xc, nz["steps"][i])
         log(f"  fp32 oracle chain on {n} windows: {time.time() - t0:.0f} s of CPU ({torch.get_num_threads()} threads)")
+        torch.set_num_threads(nt0)
         for form, m in models.items():
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
