@@ -14,9 +14,12 @@
 // transposed with the keys of each group of 16 in exactly that (half, slot) order.
 // The attention matrix itself is never written (the reference returns and discards it, TM:95,223).
 //
-// K (4 chunks of 64 of d_k) and then V^T (4 chunks of 64 of d_v) stream through a double-buffered
+// K (16 / CH chunks of 16 CH of d_k) and then V^T (16 / CH chunks of 16 CH of d_v) stream through a double-buffered
 // LDS ring as contiguous kilobyte fragments; Q fragments go global -> registers (each is used by one
-// wave only).  8 phases, one barrier each; the next phase's loads are in flight during the MFMAs.
+// wave only).  32 / CH phases, one barrier each; the next phase's loads are in flight during the MFMAs.
+// CH = 4: 64-wide chunks, 8 phases (<= 128 keys: two workgroups per CU; the fused T = 120 kernel).  CH = 2: 32-wide chunks, 16 phases —
+// the long window (7 key tiles), whose 64-wide stages (2 x 56 KiB) left room for ONE four-wave workgroup per CU, one wave per SIMD with
+// nothing to run in its waits; at 2 x 28 KiB two workgroups share a CU.  Same k order, same bits.
 #pragma once
 #include <type_traits>
 
@@ -38,11 +41,22 @@ struct AttnArgs {
 // QREG: the Q fragments are not read from global memory but handed over in registers by the caller
 // (the fused kernel computes the Q projection last and keeps it): qreg_h/qreg_l[2*i + jj] is the B-operand
 // fragment of k-step 2*i + jj in accumulator order, the order in which K is stored.
-template <int KT, int NP, bool QREG = false>
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_phases(F& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_phases<N, F, I + 1>(f);
+    }
+}
+
+template <int KT, int NP, bool QREG = false, int CH = 4>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock, char* smem,
                                           const bf16x8* qreg_h = nullptr, const bf16x8* qreg_l = nullptr) {
-    constexpr int NCH = KT * NP;                  // 16-byte chunks per thread per phase
-    constexpr int STAGE_BYTES = KT * NP * 4096;   // K chunk: KT tiles x NP planes x 4 k-steps x 1 KiB
+    static_assert((CH == 4 || CH == 2) && (KT * NP * CH) % 4 == 0, "chunk width");
+    constexpr int NCH = KT * NP * CH / 4;            // 16-byte chunks per thread per phase
+    constexpr int STAGE_BYTES = KT * NP * CH * 1024;  // K chunk: KT tiles x NP planes x CH k-steps x 1 KiB
+    constexpr int NKP = 16 / CH;                      // K phases (then as many V^T phases)
+    constexpr int DT = CH / 2;                        // d_v tiles per V^T phase
     constexpr int Lp = KT * 32;
     const int wave = wave_id_uniform();
     const int lane = threadIdx.x & 63;
@@ -53,19 +67,19 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
 
     auto stage_src = [&](int ph, int j) -> const u32x4* {
         const int blk = j * 4 + wave;
-        if (ph < 4) {
-            const int ks = blk & 3, t2 = blk >> 2;
+        if (ph < NKP) {
+            const int ks = blk % CH, t2 = blk / CH;
             const int p = t2 / KT, kt = t2 % KT;
-            return (const u32x4*)(a.k + (size_t)p * a.plane) + (((size_t)bh * KT + kt) * 16 + 4 * ph + ks) * 64 + lane;
+            return (const u32x4*)(a.k + (size_t)p * a.plane) + (((size_t)bh * KT + kt) * 16 + CH * ph + ks) * 64 + lane;
         } else {
             const int kg = blk % (2 * KT), t2 = blk / (2 * KT);
-            const int p = t2 >> 1, dt2 = t2 & 1;
+            const int p = t2 / DT, dt2 = t2 % DT;
             return (const u32x4*)(a.v + (size_t)p * a.plane) +
-                   (((size_t)bh * 8 + 2 * (ph - 4) + dt2) * (2 * KT) + kg) * 64 + lane;
+                   (((size_t)bh * 8 + DT * (ph - NKP) + dt2) * (2 * KT) + kg) * 64 + lane;
         }
     };
     auto q_src = [&](int dc, int ks, int p) -> const u32x4* {
-        return (const u32x4*)(a.q + (size_t)p * a.plane) + (((size_t)bh * KT + qt) * 16 + 4 * dc + ks) * 64 + lane;
+        return (const u32x4*)(a.q + (size_t)p * a.plane) + (((size_t)bh * KT + qt) * 16 + CH * dc + ks) * 64 + lane;
     };
 
     f32x16 s[KT];
@@ -75,7 +89,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
         for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
     bf16x8 phi[KT][2], plo[KT][2];
 
-    u32x4 qb[2][4][NP];  // Q fragments of the current / next d_k chunk (static ping-pong)
+    u32x4 qb[2][CH][NP];  // Q fragments of the current / next d_k chunk (static ping-pong)
     // K / V^T chunks travel global -> LDS by LDS-DMA (16 B per lane at wave-uniform base + 16*lane: the
     // fragment image itself), one phase ahead of the MFMAs; two slots, so two workgroups fit per CU.
     auto dma_phase = [&](int ph, int slot) {
@@ -88,7 +102,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
     dma_phase(0, 0);
     if constexpr (!QREG) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
             for (int p = 0; p < NP; ++p) qb[0][ks][p] = *q_src(0, ks, p);
     }
@@ -101,32 +115,32 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if constexpr (ph < 7) dma_phase(ph + 1, buf ^ 1);
-        if constexpr (ph < 3 && !QREG) {
+        if constexpr (ph < 2 * NKP - 1) dma_phase(ph + 1, buf ^ 1);
+        if constexpr (ph < NKP - 1 && !QREG) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) qb[(ph + 1) & 1][ks][p] = *q_src(ph + 1, ks, p);
         }
         __builtin_amdgcn_sched_barrier(0);  // loads stay above the MFMAs (hipcc would sink them to their use)
         const char* sb = smem + (size_t)buf * STAGE_BYTES + lane * 16;
-        if constexpr (ph < 4) {
+        if constexpr (ph < NKP) {
             // S^T += K_chunk x Q_chunk^T
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < CH; ++ks) {
                 bf16x8 qh, ql;
                 if constexpr (QREG) {
-                    qh = qreg_h[4 * (ph < 4 ? ph : 0) + ks];
-                    ql = qreg_l[4 * (ph < 4 ? ph : 0) + ks];
+                    qh = qreg_h[CH * (ph < NKP ? ph : 0) + ks];
+                    ql = qreg_l[CH * (ph < NKP ? ph : 0) + ks];
                 } else {
                     qh = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][0]);
                     ql = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][NP - 1]);
                 }
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
-                    const bf16x8 kh = *(const bf16x8*)(sb + ((0 * KT + kt) * 4 + ks) * 1024);
+                    const bf16x8 kh = *(const bf16x8*)(sb + ((0 * KT + kt) * CH + ks) * 1024);
                     if constexpr (NP == 2) {
-                        const bf16x8 kl = *(const bf16x8*)(sb + ((1 * KT + kt) * 4 + ks) * 1024);
+                        const bf16x8 kl = *(const bf16x8*)(sb + ((1 * KT + kt) * CH + ks) * 1024);
                         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, s[kt], 0, 0, 0);
                         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, s[kt], 0, 0, 0);
                     }
@@ -134,7 +148,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
                 }
             }
         }
-        if constexpr (ph == 3) {
+        if constexpr (ph == NKP - 1) {
             // softmax over keys (TM:82); lane (col, hf) holds keys 32kt + 8(r>>2) + 4hf + (r&3)
             float mx = -INFINITY;
 #pragma unroll
@@ -167,11 +181,11 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
                         plo[kt][jj][e] = y;
                     }
         }
-        if constexpr (ph >= 4) {
-            // O^T[64 of d_v][32 queries] = V^T_chunk x P
-            f32x16 o[2];
+        if constexpr (ph >= NKP) {
+            // O^T[32 DT of d_v][32 queries] = V^T_chunk x P
+            f32x16 o[DT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < DT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 #pragma unroll
@@ -179,10 +193,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
                 const bf16x8 ph_ = phi[kg >> 1][kg & 1];
                 const bf16x8 pl_ = plo[kg >> 1][kg & 1];
 #pragma unroll
-                for (int dt2 = 0; dt2 < 2; ++dt2) {
-                    const bf16x8 vh = *(const bf16x8*)(sb + ((0 * 2 + dt2) * (2 * KT) + kg) * 1024);
+                for (int dt2 = 0; dt2 < DT; ++dt2) {
+                    const bf16x8 vh = *(const bf16x8*)(sb + ((0 * DT + dt2) * (2 * KT) + kg) * 1024);
                     if constexpr (NP == 2) {
-                        const bf16x8 vl = *(const bf16x8*)(sb + ((1 * 2 + dt2) * (2 * KT) + kg) * 1024);
+                        const bf16x8 vl = *(const bf16x8*)(sb + ((1 * DT + dt2) * (2 * KT) + kg) * 1024);
                         o[dt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph_, o[dt2], 0, 0, 0);
                         o[dt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl_, o[dt2], 0, 0, 0);
                     }
@@ -193,7 +207,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
                 const int b = bh / a.H, h = bh % a.H;
                 const int m = b * Lp + qt * 32 + col;
 #pragma unroll
-                for (int dt2 = 0; dt2 < 2; ++dt2)
+                for (int dt2 = 0; dt2 < DT; ++dt2)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         float v[8];
@@ -201,25 +215,24 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
                         for (int c = 0; c < 8; ++c) v[c] = o[dt2][8 * jj + c];
                         u32x4 hi, lo;
                         split8(v, hi, lo);
-                        const size_t idx = acc_slot(m, h * 256 + (2 * (ph - 4) + dt2) * 32, jj, hf, a.HD16);
+                        const size_t idx = acc_slot(m, h * 256 + (DT * (ph - NKP) + dt2) * 32, jj, hf, a.HD16);
                         *(u32x4*)(a.o + idx) = hi;
                         if constexpr (NP == 2) *(u32x4*)(a.o + a.o_plane + idx) = lo;
                     }
             }
         }
     };
-    phase(std::integral_constant<int, 0>{});
-    phase(std::integral_constant<int, 1>{});
-    phase(std::integral_constant<int, 2>{});
-    phase(std::integral_constant<int, 3>{});
-    phase(std::integral_constant<int, 4>{});
-    phase(std::integral_constant<int, 5>{});
-    phase(std::integral_constant<int, 6>{});
-    phase(std::integral_constant<int, 7>{});
+    static_phases<2 * NKP>(phase);
 }
 
+#ifndef EGOEGO_ATTN_CH4
+#define EGOEGO_ATTN_CH4 0  // (A/B knob of variant builds: 1 = 64-wide chunks for the long window too, one workgroup per CU — the form up to round 5)
+#endif
+template <int KT, int NP> constexpr int attn_chunk() { return (KT <= 4 || EGOEGO_ATTN_CH4 || (KT * NP * 2) % 4 != 0) ? 4 : 2; }
+template <int KT, int NP> constexpr int attn_smem() { return 2 * KT * NP * attn_chunk<KT, NP>() * 1024; }
+
 template <int KT, int NP>
-__global__ __launch_bounds__(256, (KT <= 4 ? 2 : 1)) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (attn_smem<KT, NP>() <= 80 * 1024 && !(EGOEGO_ATTN_CH4 && KT > 4) ? 2 : 1)) void attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body<KT, NP>(a, (int)blockIdx.y + a.bh0, (int)blockIdx.x, smem);
+    attn_body<KT, NP, false, attn_chunk<KT, NP>()>(a, (int)blockIdx.y + a.bh0, (int)blockIdx.x, smem);
 }

@@ -440,7 +440,7 @@ static int launch_gemm(const GemmOperands& g, const Epi& epi, hipStream_t s) {
 template <int KT, int NP>
 static int launch_attn_kt(const AttnArgs& a, int BH, hipStream_t s) {
     auto kern = attn_kernel<KT, NP>;
-    constexpr int smem = 2 * KT * NP * 4096;
+    constexpr int smem = attn_smem<KT, NP>();
     static DevOnce once;
     if (once.pending()) {
         HIP_TRY(allow_smem(kern, smem));

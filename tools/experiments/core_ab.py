@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on the long window (T = 196): dump what this build computes, or compare two dumps.
-    python tools/experiments/core_ab.py dump out.pt       (EGOEGO_PERFDEBUG_TAG=<tag> selects a variant build)
+    python tools/experiments/core_ab.py dump out.pt       (EGOEGO_PERFDEBUG_TAG=<tag> selects a variant build; AB_PRECS=3 the precisions, default 9,8)
     python tools/experiments/core_ab.py cmp a.pt b.pt"""
 import os
 import sys
@@ -22,7 +22,7 @@ from egoego_release_amd.model import CondGaussianDiffusion  # noqa: E402
 out = {}
 for T in (196, 150):
     cfg = ModelConfig(max_timesteps=T + 1)
-    for prec in (9, 8):
+    for prec in [int(v) for v in os.environ.get("AB_PRECS", "9,8").split(",")]:
         m = CondGaussianDiffusion(**cfg.ctor_kwargs())
         m.load_state_dict(make_weights(cfg, 0), strict=False)
         m.hip_precision, m.hip_probe_at_pack = prec, False
