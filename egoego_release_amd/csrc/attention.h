@@ -25,6 +25,10 @@
 
 #include "common.h"
 
+#ifndef EGOEGO_ATTN_LIBM_SOFTMAX
+#define EGOEGO_ATTN_LIBM_SOFTMAX 0  // (A/B knob of variant builds: 1 = libm expf and a division per probability, the form up to round 5)
+#endif
+
 struct AttnArgs {
     const __bf16* q;  // [B][H][L/32][16][2][32][8], pre-scaled by 1/temperature
     const __bf16* k;  // same layout
@@ -160,15 +164,27 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
                     mx = fmaxf(mx, s[kt][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // e^(s - max) as one fma and one v_exp_f32 (relative error ~1e-6 for |s - max| < 30 — an eighth of the step of the
+            // split-bf16 probabilities it feeds), and ONE reciprocal of the row sum instead of a division per probability: libm's
+            // expf and IEEE division are ~20 instructions per probability, 2 x 112 of them per lane on the long window
+            constexpr float LOG2E = 1.4426950408889634f;
+            const float mxl = mx * LOG2E;
+            (void)mxl;
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#if EGOEGO_ATTN_LIBM_SOFTMAX
                     s[kt][r] = expf(s[kt][r] - mx);
+#else
+                    s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], LOG2E, -mxl));  // (masked keys: exp2(-inf) = 0)
+#endif
                     sum += s[kt][r];
                 }
             sum += __shfl_xor(sum, 32);
+            const float inv_sum = 1.0f / sum;
+            (void)inv_sum;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -176,7 +192,11 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         __bf16 x, y;
+#if EGOEGO_ATTN_LIBM_SOFTMAX
                         split_bf16(s[kt][8 * jj + e] / sum, x, y);
+#else
+                        split_bf16(s[kt][8 * jj + e] * inv_sum, x, y);
+#endif
                         phi[kt][jj][e] = x;
                         plo[kt][jj][e] = y;
                     }
@@ -234,5 +254,12 @@ template <int KT, int NP> constexpr int attn_smem() { return 2 * KT * NP * attn_
 template <int KT, int NP>
 __global__ __launch_bounds__(256, (attn_smem<KT, NP>() <= 80 * 1024 && !(EGOEGO_ATTN_CH4 && KT > 4) ? 2 : 1)) void attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body<KT, NP, false, attn_chunk<KT, NP>()>(a, (int)blockIdx.y + a.bh0, (int)blockIdx.x, smem);
+#ifndef EGOEGO_ATTN_NOREMAP
+#define EGOEGO_ATTN_NOREMAP 0  // (A/B knob of variant builds: 1 = hardware block order, the query blocks of a (window, head) on different XCDs)
+#endif
+    // the query blocks of one (window, head) stream the same K / V^T images: consecutive remapped ids = one XCD, started together, so
+    // the second read of a chunk comes out of that XCD's L2
+    const int nqb = (int)gridDim.x;
+    const int lid = EGOEGO_ATTN_NOREMAP ? (int)(blockIdx.y * nqb + blockIdx.x) : xcd_remap((int)(blockIdx.y * nqb + blockIdx.x), nqb * (int)gridDim.y);
+    attn_body<KT, NP, false, attn_chunk<KT, NP>()>(a, lid / nqb + a.bh0, lid % nqb, smem);
 }

@@ -248,3 +248,12 @@ EG_D void philox_normal4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, u
     const float s1 = __builtin_amdgcn_sinf(u3), c1f = __builtin_amdgcn_cosf(u3);
     out[0] = ra * c0f; out[1] = ra * s0; out[2] = rb * c1f; out[3] = rb * s1;
 }
+
+// Blocks that share an activation tile (same token block, different feature blocks) are made
+// consecutive in the remapped id and land on ONE XCD (hardware places block b on XCD b % 8), so the
+// tile is fetched into one L2 instead of eight.  Bijective for any grid size.
+EG_D int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

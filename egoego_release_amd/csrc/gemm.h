@@ -49,15 +49,6 @@ struct GemmOperands {
     int kcount;  // k-blocks to contract, starting at w / a (K16 stays the row stride of both operands); 0 = all K16
 };
 
-// Blocks that share an activation tile (same token block, different feature blocks) are made
-// consecutive in the remapped id and land on ONE XCD (hardware places block b on XCD b % 8), so the
-// tile is fetched into one L2 instead of eight.  Bijective for any grid size.
-EG_D int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
 // Block-id -> (feature block, token block).  After xcd_remap every XCD owns a contiguous range of ids;
 // inside it, ids walk groups of 8 token blocks x all feature blocks (token fastest), so the ~32 blocks
 // resident on an XCD at any time form an 8-token-block x 4-feature-block patch whose operand tiles are
