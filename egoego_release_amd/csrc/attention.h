@@ -263,3 +263,215 @@ __global__ __launch_bounds__(256, (attn_smem<KT, NP>() <= 80 * 1024 && !(EGOEGO_
     const int lid = EGOEGO_ATTN_NOREMAP ? (int)(blockIdx.y * nqb + blockIdx.x) : xcd_remap((int)(blockIdx.y * nqb + blockIdx.x), nqb * (int)gridDim.y);
     attn_body<KT, NP, false, attn_chunk<KT, NP>()>(a, lid / nqb + a.bh0, lid % nqb, smem);
 }
+
+// ---- The long window (KT = 7 key tiles, <= 224 tokens) on EIGHT waves: one workgroup per (window, head) ------------------------------
+// attn_kernel<7> runs two four-wave workgroups per (window, head) — each streams the whole K and V^T image (2 x 448 KiB through L2 -> LDS
+// per pair) with ONE chunk of prefetch distance, and waits for it in every one of its sixteen phases (round 5's ablations: HISTORY R5).
+// Here wave w owns query tile w (wave 7 only helps with the loads), the images cross L2 -> LDS once, and the ring has FOUR 28-KiB slots:
+// the chunk of phase p + 3 is requested at the start of phase p, so a wave waits with `vmcnt` counted for the chunks still allowed in
+// flight (gemm.h's ring discipline: counted vmcnt + lgkmcnt(0), raw s_barrier, never __syncthreads()).  The Q fragments of the next d_k
+// chunk come global -> VGPR by INLINE ASSEMBLY: hipcc drains vmcnt to 0 in front of the first use of an ordinary load's result while an
+// LDS-DMA is in flight, which would undo the ring; the asm loads are ordered by hand — issued BEFORE the phase's LDS-DMA requests, so the
+// wait that covers them leaves exactly those requests in flight.  Same k order per accumulator as attn_body: same bits.
+// What bounds it (timing-only ablations, B=256 x T=196, HISTORY R5): 200 us per launch as is, 188 without its MFMAs, 204 without its LDS
+// fragment reads, 112 without its global loads — the kernel streams Q, K, V^T in and O out, 4 bytes per value, 0.9 GB per launch = 4.6 TB/s:
+// HBM.  (At T = 120 the fused kernel keeps K, V^T and Q on the CU; a 224-key split-bf16 image pair does not fit a CU's LDS.)
+EG_D u32x4 load16_untracked(const u32x4* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int KT, int NP>
+__global__ __launch_bounds__(512, 1) void attn8_kernel(AttnArgs a) {
+    static_assert(NP == 2 && KT >= 5 && KT <= 8, "the split-bf16 long window");
+    constexpr int CH = 2, NKP = 16 / CH, NPH = 2 * NKP, NSLOT = 4;
+    constexpr int NBLK = KT * NP * CH;        // 1-KiB fragment blocks per chunk (K: [plane][key tile][k-step], V^T: [plane][key group])
+    constexpr int NCH = (NBLK + 7) / 8;       // LDS-DMA requests per wave and phase (the last block is requested more than once when 8 does not divide NBLK)
+    constexpr int STAGE_BYTES = NBLK * 1024;
+    constexpr int NQ = CH * NP;               // Q fragments per d_k chunk
+    constexpr int NST = 2 * NP;               // output stores per V^T phase
+    constexpr int Lp = KT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bh = (int)blockIdx.x + a.bh0;
+    const int wave = wave_id_uniform();
+    const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
+    const bool active = wave < KT;
+    const int qt = active ? wave : KT - 1;
+
+    auto stage_src = [&](int ph, int j) -> const u32x4* {
+        const int blk = min(j * 8 + wave, NBLK - 1);
+        if (ph < NKP) {
+            const int ks = blk % CH, t2 = blk / CH;
+            const int p = t2 / KT, kt = t2 % KT;
+            return (const u32x4*)(a.k + (size_t)p * a.plane) + (((size_t)bh * KT + kt) * 16 + CH * ph + ks) * 64 + lane;
+        } else {
+            const int kg = blk % (2 * KT), p = blk / (2 * KT);
+            return (const u32x4*)(a.v + (size_t)p * a.plane) + (((size_t)bh * 8 + (ph - NKP)) * (2 * KT) + kg) * 64 + lane;
+        }
+    };
+    auto dma_phase = [&](int ph) {
+        char* dst = smem + (size_t)(ph % NSLOT) * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)stage_src(ph, j),
+                                             (__attribute__((address_space(3))) void*)(dst + (size_t)min(j * 8 + wave, NBLK - 1) * 1024), 16, 0, 0);
+    };
+    u32x4 qb[2][CH][NP];
+    auto q_load = [&](int dc) {
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                qb[dc & 1][ks][p] = load16_untracked((const u32x4*)(a.q + (size_t)p * a.plane) + (((size_t)bh * KT + qt) * 16 + CH * dc + ks) * 64 + lane);
+    };
+
+    f32x16 s[KT];
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
+    bf16x8 phi[KT][2], plo[KT][2];
+
+    q_load(0);
+    dma_phase(0);
+    dma_phase(1);
+    dma_phase(2);
+
+    auto phase = [&](auto PHC) {
+        constexpr int ph = decltype(PHC)::value;
+        // What this wave issued AFTER the requests it needs now (its share of chunk ph; in a K phase also the Q fragments of chunk ph,
+        // which were issued in front of the requests of phase ph - 1) may stay in flight.
+        //   K phase ph >= 1: the requests of chunk ph + 2 (issued in phase ph - 1 behind the Q loads);  phase 0: chunks 1, 2
+        //   V phase: the requests of chunks ph + 1, ph + 2 and the stores of the V phases among ph - 3 .. ph - 1 (none for wave 7)
+        constexpr int d_after = (ph + 1 < NPH ? 1 : 0) + (ph + 2 < NPH ? 1 : 0);
+        constexpr int st_after = (ph - 3 >= NKP ? 1 : 0) + (ph - 2 >= NKP ? 1 : 0) + (ph - 1 >= NKP ? 1 : 0);
+        asm volatile("" ::: "memory");
+        if constexpr (ph == 0) wait_counts<2 * NCH, 0>();
+        else if constexpr (ph < NKP) wait_counts<NCH, 0>();
+        else if constexpr (st_after == 0) wait_counts<d_after * NCH, 0>();
+        else {
+            if (active) wait_counts<d_after * NCH + st_after * NST, 0>();
+            else wait_counts<d_after * NCH, 0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (ph < NKP) {
+            // the Q fragments of this chunk are in their registers now: from here on the compiler may read them
+#pragma unroll
+            for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(qb[ph & 1][ks][p]));
+        }
+        if constexpr (ph + 1 < NKP) q_load(ph + 1);
+        if constexpr (ph + 3 < NPH) dma_phase(ph + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sb = smem + (size_t)(ph % NSLOT) * STAGE_BYTES + lane * 16;
+        if constexpr (ph < NKP) {
+            if (active) {
+                // the K fragments of step i + 1 are requested before the MFMAs of step i and waited for behind them (gemm.h's discipline: an
+                // LDS wait only ever finds reads that were issued a batch of MFMAs ago; on its own hipcc reads, waits and multiplies in turn,
+                // one exposed LDS round trip per 96 MFMA clocks)
+                bf16x8 fk[2][2];
+                auto k_read = [&](int i) {
+                    const int ks = i / KT, kt = i % KT;
+                    fk[i & 1][0] = *(const bf16x8*)(sb + ((0 * KT + kt) * CH + ks) * 1024);
+                    fk[i & 1][1] = *(const bf16x8*)(sb + ((1 * KT + kt) * CH + ks) * 1024);
+                };
+                k_read(0);
+#pragma unroll
+                for (int i = 0; i < CH * KT; ++i) {
+                    const int ks = i / KT, kt = i % KT;
+                    wait_lds();  // the fragments of step i (requested in front of the previous step's MFMAs) are here ...
+                    if (i + 1 < CH * KT) k_read(i + 1);  // ... and those of step i + 1 travel behind this step's
+                    const bf16x8 qh = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][0]);
+                    const bf16x8 ql = __builtin_bit_cast(bf16x8, qb[ph & 1][ks][1]);
+                    __builtin_amdgcn_sched_barrier(0);  // (hipcc would sink the reads to their use and wait lgkmcnt(0) there)
+                    const bf16x8 kh = fk[i & 1][0], kl = fk[i & 1][1];
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, s[kt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if constexpr (ph == NKP - 1) {
+            if (active) {  // softmax over keys (TM:82), as in attn_body
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * kt + mfma32_row(r, hf);
+                        if (key >= a.L) s[kt][r] = -INFINITY;
+                        mx = fmaxf(mx, s[kt][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                constexpr float LOG2E = 1.4426950408889634f;
+                const float mxl = mx * LOG2E;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], LOG2E, -mxl));
+                        sum += s[kt][r];
+                    }
+                sum += __shfl_xor(sum, 32);
+                const float inv_sum = 1.0f / sum;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            __bf16 x, y;
+                            split_bf16(s[kt][8 * jj + e] * inv_sum, x, y);
+                            phi[kt][jj][e] = x;
+                            plo[kt][jj][e] = y;
+                        }
+            }
+        }
+        if constexpr (ph >= NKP) {
+            if (active) {
+                // O^T[32 of d_v][32 queries] = V^T_chunk x P
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+                bf16x8 fv[2][2];
+                auto v_read = [&](int kg) {
+                    fv[kg & 1][0] = *(const bf16x8*)(sb + (0 * (2 * KT) + kg) * 1024);
+                    fv[kg & 1][1] = *(const bf16x8*)(sb + (1 * (2 * KT) + kg) * 1024);
+                };
+                v_read(0);
+#pragma unroll
+                for (int kg = 0; kg < 2 * KT; ++kg) {
+                    wait_lds();
+                    if (kg + 1 < 2 * KT) v_read(kg + 1);
+                    const bf16x8 ph_ = phi[kg >> 1][kg & 1];
+                    const bf16x8 pl_ = plo[kg >> 1][kg & 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 vh = fv[kg & 1][0], vl = fv[kg & 1][1];
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph_, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl_, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph_, o, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int b = bh / a.H, h = bh % a.H;
+                const int m = b * Lp + qt * 32 + col;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = o[8 * jj + c];
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    const size_t idx = acc_slot(m, h * 256 + (ph - NKP) * 32, jj, hf, a.HD16);
+                    *(u32x4*)(a.o + idx) = hi;
+                    *(u32x4*)(a.o + a.o_plane + idx) = lo;
+                }
+            }
+        }
+    };
+    static_phases<NPH>(phase);
+}

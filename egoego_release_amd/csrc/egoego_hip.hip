@@ -451,8 +451,32 @@ static int launch_attn_kt(const AttnArgs& a, int BH, hipStream_t s) {
     return 0;
 }
 
+// the long window in split-bf16: one eight-wave workgroup per (window, head) with a four-slot ring (attention.h, round 5);
+// EGOEGO_ATTN_WG4=1 (variant builds) keeps the two four-wave workgroups for A/B runs
+#ifndef EGOEGO_ATTN_WG4
+#define EGOEGO_ATTN_WG4 0
+#endif
+template <int KT>
+static int launch_attn8_kt(const AttnArgs& a, int BH, hipStream_t s) {
+    auto kern = attn8_kernel<KT, 2>;
+    constexpr int smem = 4 * KT * 2 * 2 * 1024;
+    static DevOnce once;
+    if (once.pending()) {
+        HIP_TRY(allow_smem(kern, smem));
+        once.done();
+    }
+    kern<<<dim3(BH), dim3(512), smem, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int NP>
 static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
+    if constexpr (NP == 2) {
+        // (same bits either way; below one workgroup per CU the two four-wave workgroups per (window, head) spread over twice the CUs:
+        // B=1 0.447 against 0.453 ms per step)
+        if (KT == 7 && !EGOEGO_ATTN_WG4 && BH >= 256) return launch_attn8_kt<7>(a, BH, s);
+    }
     switch (KT) {
         case 1: return launch_attn_kt<1, NP>(a, BH, s);
         case 2: return launch_attn_kt<2, NP>(a, BH, s);
