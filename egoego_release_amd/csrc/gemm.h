@@ -241,7 +241,7 @@ struct GemmBody {
         struct ActFr { bf16x8 h[TT], l[TT]; };
         struct WFr { bf16x8 h[FH], l[FH]; };
         // perf-debug, compile-time so the shipped loop carries no branches: -DEGOEGO_ABLATE_MAINLOOP=bits
-        // (1 = no global->LDS loads, 8 = no LDS fragment reads, 16 = no waits / barriers)
+        // (1 = no global->LDS loads, 8 = no LDS fragment reads, 16 = no waits / barriers, 32 = no MFMAs)
         constexpr bool loads_on = !(EGOEGO_ABLATE_MAINLOOP & 1), reads_on = !(EGOEGO_ABLATE_MAINLOOP & 8), sync_on = !(EGOEGO_ABLATE_MAINLOOP & 16);
         auto read_act = [&](int slot, int ks, ActFr& f) {
             if (!reads_on) return;
@@ -279,7 +279,8 @@ struct GemmBody {
                 for (int i = 0; i < FH; ++i)
 #pragma unroll
                     for (int j = 0; j < TT; ++j) {
-                        mma_part<NP, C::ACT_ROWS>(part, acc[half * FH + i][j], w.h[i], w.l[i], a.h[j], a.l[j]);
+                        if constexpr (!(EGOEGO_ABLATE_MAINLOOP & 32)) mma_part<NP, C::ACT_ROWS>(part, acc[half * FH + i][j], w.h[i], w.l[i], a.h[j], a.l[j]);
+                        else asm volatile("" ::"v"(w.h[i]), "v"(w.l[i]), "v"(a.h[j]), "v"(a.l[j]));
                         const int n = (part * FH + i) * TT + j;
                         if (n == 0) after_first();
                         reads(n);
