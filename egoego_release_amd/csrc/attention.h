@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256, (attn_smem<KT, NP>() <= 80 * 1024 && !(EGOEGO_
 // flight (gemm.h's ring discipline: counted vmcnt + lgkmcnt(0), raw s_barrier, never __syncthreads()).  The Q fragments of the next d_k
 // chunk come global -> VGPR by INLINE ASSEMBLY: hipcc drains vmcnt to 0 in front of the first use of an ordinary load's result while an
 // LDS-DMA is in flight, which would undo the ring; the asm loads are ordered by hand — issued BEFORE the phase's LDS-DMA requests, so the
-// wait that covers them leaves exactly those requests in flight.  Same k order per accumulator as attn_body: same bits.
+// wait that covers them leaves exactly those requests in flight (tools/check_untracked_loads.py verifies on the generated assembly that
+// nothing touches a destination register of such a load before a vmcnt wait).  Same k order per accumulator as attn_body: same bits.
 // What bounds it (timing-only ablations, B=256 x T=196, HISTORY R5): 200 us per launch as is, 188 without its MFMAs, 204 without its LDS
 // fragment reads, 112 without its global loads — the kernel streams Q, K, V^T in and O out, 4 bytes per value, 0.9 GB per launch = 4.6 TB/s:
 // HBM.  (At T = 120 the fused kernel keeps K, V^T and Q on the CU; a 224-key split-bf16 image pair does not fit a CU's LDS.)
