@@ -896,7 +896,7 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             // --- softmax(QK^T / sqrt(dk)) V, heads merged (TM:75-88)
             if (!core8) {
                 ProfScope ps(c, EGOEGO_K_ATTN, s);
-                c->last_kernel[EGOEGO_K_ATTN] = "attn_kernel";
+                c->last_kernel[EGOEGO_K_ATTN] = (NP == 2 && g.KT == 7 && !EGOEGO_ATTN_WG4 && nw * H >= 256) ? "attn8_kernel" : "attn_kernel";
                 if (int r = launch_attn<NP>(aa, g.KT, nw * H, s)) return r;
             }
         }

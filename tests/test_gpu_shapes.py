@@ -127,6 +127,32 @@ def test_b256_t196_against_oracle(prec):
     assert (zz[:2] - z).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize("T", [196, 150])
+def test_split_bf16_long_window_same_bits_on_both_attention_forms(T):
+    """Split-bf16 windows of 129-224 tokens: from one workgroup per CU on (B x H >= 256) the attention core is attn8_kernel (eight waves per
+    (window, head), K / V^T once through a four-slot ring, Q by untracked loads), below it two four-wave workgroups per (window, head)
+    (attention.h).  Same k order per accumulator: the windows of a 70-window call equal, bit for bit, the same windows run three at a time —
+    one denoiser pass and six Philox steps."""
+    cfg, sd, m = _model(T, precision=_lib.PREC_BF16X3)
+    eng = m.hip_engine()
+    B = 70
+    x, xc, g = _inputs(B, T, 77)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(6)).cuda()
+    big = m.denoise(x, t, xc)
+    assert eng.last_kernel("attn") == "attn8_kernel"
+    chain = x.clone()
+    eng.sample_loop_(chain, xc, 400, 6, noise_mode=_lib.NOISE_PHILOX, seed=9)
+    for w0 in (0, 33, 67):
+        sl = slice(w0, w0 + 3)
+        small = m.denoise(x[sl].contiguous(), t[sl].contiguous(), xc[sl].contiguous())
+        assert torch.equal(small, big[sl]), (T, w0, float((small - big[sl]).abs().max()))
+        assert eng.last_kernel("attn") == "attn_kernel"
+    a = x[:3].contiguous().clone()
+    eng.sample_loop_(a, xc[:3].contiguous(), 400, 6, noise_mode=_lib.NOISE_PHILOX, seed=9)
+    assert torch.equal(a, chain[:3])
+    assert torch.isfinite(big).all()
+
+
 def test_b256_t196_ddim_50_steps(prec):
     """configs[3]'s sampler at its real size: 50-step DDIM over B=256 windows of 196 frames.  No reference DDIM
     exists (SURVEY.md §8f #3): two windows are checked against the oracle's restatement of the published update."""
