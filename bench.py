@@ -371,6 +371,7 @@ def main():
                            "LDS-DMA chunks (precision 9: all three contractions on int8 slices, one integer chain per head in fc, LayerNorm-1 rows and hidden rows resident in LDS)",
             "layer_tail_i8_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands; fc split-bf16, FFN on int8 slices in two passes into one int32 accumulator",
             "layer_tail_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands, split-bf16",
+            "layer_tail_kernel:128": "the same three GEMMs per 128 tokens, one eight-wave workgroup per CU, LDS-ring operands, split-bf16",
             "gemm_kernel:EpiResLN": "fc + residual + LayerNorm alone (unfused small-batch form; FFN-1 / FFN-2 are separate launches not in this figure)"}
         # the peak of the MFMAs the kernel issues: all int8 (precision 9), fc bf16 + FFN int8 (precision 8: the two halves of its
         # FLOPs at 2.5 and 5 P, i.e. 3333 T together), all bf16 (precisions 3, 1)

@@ -262,9 +262,10 @@ __global__ __launch_bounds__(CQK::NT, CQK::MINW) void qkv_attn_kernel(GemmOperan
 }
 
 // ------------------------------------------------------------------------------------ fused layer tail
-// One workgroup takes a block of tokens through fc+residual+LayerNorm -> FFN-1+ReLU -> FFN-2+residual+LayerNorm.  It is
-// launched on 64-token blocks with 4 waves and two workgroups per CU, so that one's epilogues and barrier waits overlap the
-// other's main loops (measured against one 8-wave workgroup per 128 tokens: -4 %, although weights are streamed twice as often).
+// One workgroup takes a block of tokens through fc+residual+LayerNorm -> FFN-1+ReLU -> FFN-2+residual+LayerNorm.  Two tilings of
+// the same arithmetic (same bits): 64-token blocks with 4 waves and two workgroups per CU, so that one's epilogues and barrier waits
+// overlap the other's main loops; from one workgroup per CU on (round 5), 128-token blocks with 8 waves, which stream the weights half
+// as often (the dispatch site has the measurements).
 // Rows are independent, so the tile a phase reads is exactly the tile the previous phase of the SAME workgroup
 // wrote: it comes back from L2 instead of HBM, and two kernel boundaries per layer disappear.
 template <class C, class ELN, class ETI>
@@ -981,6 +982,31 @@ static int run_chunk_np(egoego_ctx* c, const Geometry& g, const Workspace& w, co
             GemmOperands g3{L.w_2, (size_t)N_MODEL * N_MODEL, w.F, w.h_plane, N_MODEL / 16, 1, nb, b0 EG_DBG(, g_ablate, g_trace ? g_trace + 8192 : nullptr)};
             EpiResLN<NP, 4, 64> e3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
             e3.outlier = om2; e3.outlier_rows = g.Mvalid;
+            // From one workgroup per CU on: ONE eight-wave workgroup per 128 tokens and CU instead of two four-wave ones per 64 — the weight
+            // tiles (16 of a stage's 18 fragment blocks) cross L2 -> LDS once per 128 tokens; its epilogues have no second workgroup to hide
+            // behind, and it still wins since the operand stream is the largest item of this kernel (round 5's ablations: 233 us as
+            // shipped, 148 without the stream): 215-218 against 231-236 us per launch at B=256 x T=120, 413-421 against 426-429 at T=196,
+            // same bits.  (Round 2 had measured this form 4 % SLOWER, on a two-stage ring.)  EGOEGO_TAIL128_BF16=0: variant builds, A/B.
+#ifndef EGOEGO_TAIL128_BF16
+#define EGOEGO_TAIL128_BF16 1
+#endif
+            if (EGOEGO_TAIL128_BF16 && rows % 128 == 0 && row0 % 128 == 0 && rows / 128 >= 256) {
+                g1.ntb = g2.ntb = g3.ntb = rows / 128;
+                g1.tblk0 = g2.tblk0 = g3.tblk0 = row0 / 128;
+                EpiResLN<NP, 4, 128> f1{L.b_fc, w.hA, w.h_plane, L.ln1_g, L.ln1_b, io.row_mask, w.hB, w.h_plane, 1e-5f};
+                EpiResLN<NP, 4, 128> f3{L.b_2, w.hB, w.h_plane, L.ln2_g, L.ln2_b, io.row_mask, w.hA, w.h_plane, 1e-5f, q8p, w.h_plane, w.hA_scale};
+                f3.outlier = om2; f3.outlier_rows = g.Mvalid;
+                auto kern = layer_tail_kernel<CfgB<NP>, EpiResLN<NP, 4, 128>, EpiTiled<true, NP>>;
+                static DevOnce once;
+                if (once.pending()) {
+                    HIP_TRY(allow_smem(kern, CfgB<NP>::SMEM_BYTES));
+                    once.done();
+                }
+                c->last_kernel[EGOEGO_K_FC_LN] = "layer_tail_kernel:128";
+                kern<<<dim3(rows / 128), dim3(CfgB<NP>::NT), CfgB<NP>::SMEM_BYTES, s>>>(g1, f1, g2, e2, g3, f3);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             auto kern = layer_tail_kernel<CfgBs<NP>, EpiResLN<NP, 4, 64>, EpiTiled<true, NP>>;
             static DevOnce once;
             if (once.pending()) {
