@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on the long window (T = 196): dump what this build computes, or compare two dumps.
-    python tools/experiments/core_ab.py dump out.pt       (EGOEGO_PERFDEBUG_TAG=<tag> selects a variant build; AB_PRECS=3 the precisions, default 9,8)
+    python tools/experiments/core_ab.py dump out.pt       (EGOEGO_PERFDEBUG_TAG=<tag> selects a variant build; AB_PRECS=3 the precisions, default 9,8; AB_WINDOWS=120 / AB_BATCHES=1,130 the shapes, default 196,150 / 1,5,67)
     python tools/experiments/core_ab.py cmp a.pt b.pt"""
 import os
 import sys
@@ -20,7 +20,7 @@ if "EGOEGO_PERFDEBUG_TAG" in os.environ:
 from egoego_release_amd.model import CondGaussianDiffusion  # noqa: E402
 
 out = {}
-for T in (196, 150):
+for T in [int(v) for v in os.environ.get("AB_WINDOWS", "196,150").split(",")]:
     cfg = ModelConfig(max_timesteps=T + 1)
     for prec in [int(v) for v in os.environ.get("AB_PRECS", "9,8").split(",")]:
         m = CondGaussianDiffusion(**cfg.ctor_kwargs())
@@ -28,7 +28,7 @@ for T in (196, 150):
         m.hip_precision, m.hip_probe_at_pack = prec, False
         m = m.cuda()
         eng = m.hip_engine()
-        for B in (1, 5, 67):
+        for B in [int(v) for v in os.environ.get("AB_BATCHES", "1,5,67").split(",")]:
             g = torch.Generator().manual_seed(B)
             x, xc = torch.randn(B, T, 198, generator=g).cuda(), torch.randn(B, T, 198, generator=g).cuda()
             t = torch.randint(0, 1000, (B,), generator=g).cuda()
