@@ -14,7 +14,8 @@ bad = 0
 for (B, T, prec, steps) in ((256, 120, 9, 150), (128, 120, 9, 150), (64, 120, 9, 150), (32, 120, 9, 200), (24, 120, 9, 200), (16, 120, 9, 200), (8, 120, 9, 200), (1, 120, 9, 300),
                             (300, 100, 9, 60), (5, 127, 9, 60), (256, 196, 9, 40), (32, 196, 9, 60), (48, 60, 9, 100),  # the default precision: every batch-size tier of its dispatch
                             (256, 120, 8, 150), (64, 120, 8, 150), (7, 120, 8, 100), (300, 100, 8, 60), (5, 127, 8, 60), (256, 196, 8, 40), (32, 120, 8, 200), (128, 120, 8, 150), (32, 196, 8, 60), (1, 120, 8, 200), (48, 60, 8, 100),
-                            (256, 120, 3, 150), (64, 120, 3, 100), (96, 30, 3, 100), (256, 120, 1, 100)):
+                            (256, 120, 3, 150), (64, 120, 3, 100), (96, 30, 3, 100), (256, 120, 1, 100),
+                            (256, 196, 3, 60), (70, 150, 3, 80), (32, 196, 3, 80), (1, 196, 3, 100)):  # split-bf16 long windows: the eight-wave ring (counted vmcnt, untracked loads) and the four-wave pair
     cfg = ModelConfig(max_timesteps=T + 1)
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
     m.load_state_dict(make_weights(cfg, 0), strict=False)
