@@ -340,7 +340,7 @@ def test_small_jobs_run_split_bf16_unprobed_and_the_verdict_is_cached(tmp_path, 
 def test_whole_chain_at_the_metrics_size_b256(trained):
     """the WHOLE 1000-step chain at B = 256 (BASELINE configs[2]; its first 64 windows = configs[1]) in what `auto`
     picks — for the initialisation and for the trained-like checkpoint — against split-bf16 with the same Philox draws, per window;
-    one window against the fp32 CPU oracle with the oracle's draws (tools/chain_tail_b256.py; all seeds, both window lengths
+    four windows against the fp32 CPU oracle with the oracle's draws (tools/chain_tail_b256.py; all seeds, both window lengths
     and every int8 form: profiles/r05_chain_tail_b256.txt).
     The initialisation's chain does not amplify operand rounding (whole chain / one forward ~1) and runs "9 as is" inside the bar on all 256
     windows; the trained-like checkpoint's does (5-10x), and `auto` answers with split-bf16 (plan.AMPLIFICATION_LIMIT)."""
@@ -359,7 +359,7 @@ def test_whole_chain_at_the_metrics_size_b256(trained):
     sd, info = trained
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        res = chain_tail(sd, T, 256, ("auto", "8pn"), n_oracle=1, log=lambda s: print(s))
+        res = chain_tail(sd, T, 256, ("auto", "8pn"), n_oracle=4, log=lambda s: print(s))
         sens = sensitivity(sd, T, 256, [1e-6], log=lambda s: print(s))["eps"][1e-6]
     r = res["auto"]
     amp = {k: v for k, v in r["probe"].items() if k.endswith("amplification")}
