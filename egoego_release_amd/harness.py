@@ -14,9 +14,9 @@ Mirrors, with the same names and argument meaning,
 Differences from the reference, on purpose: everything stays on the GPU (the reference round-trips through
 numpy twice per window, M:362-368, 435-440); the 1000 diffusion steps of a window run inside ONE call of the
 HIP sample loop, with the per-step overwrite of the first 10 frames (M:395-397) done by the step kernel's
-`prefix` argument; 6D -> matrix uses the HIP kernel.  No reference oracle can run here (pytorch3d /
-human_body_prior / SMPL-H are absent): parity for this tier is against oracle/harness_oracle.py, an
-independent numpy + scipy restatement, and is "unpinned" in the sense of SURVEY.md §8c.
+`prefix` argument; 6D -> matrix uses the HIP kernel.  Parity: the loop and the conversion chain are checked against a run of
+the reference's own code on its demo trajectory (tests/golden/make_window_loop_golden.py -> tests/test_window_loop_golden.py);
+only the bodies of the pytorch3d.transforms functions (absent here) are unpinned in the sense of SURVEY.md §8c.
 """
 import numpy as np
 import ctypes as C

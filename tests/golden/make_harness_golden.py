@@ -11,8 +11,8 @@ Runs only in the authoring container (/root/reference present).  What of the har
     called unbound on a stand-in `self` that carries the reference's real statistics
     test_data/ares/cano_min_max_mean_std_data_window_120.p exactly as the dataset loads them (:236-239).
 
-What is NOT runnable (pytorch3d / human_body_prior / SMPL-H absent): fk_smpl, quat_ik_torch, convert_model_res_to_data,
-the sliding-window loop as a whole.  Those stay restated in oracle/harness_oracle.py and cross-checked against scipy.
+fk_smpl, quat_ik_torch, convert_model_res_to_data and the sliding-window loop as a whole need `pytorch3d.transforms`: they are
+run by make_window_loop_golden.py (next to this file) with those nine function bodies supplied from scipy.
 
 Outputs are data only (inputs + expected outputs + the two statistics vectors): tests/golden/harness_golden.npz.
 
