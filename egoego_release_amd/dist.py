@@ -161,7 +161,7 @@ def harness_sharded(model, ds, head_pose, sample_bs=1, seed=0, parents=None, gro
             model.philox_seed = int(seed) * 1000003 + 11  # (+ the window index inside the harness)
             try:
                 return harness.full_body_gen_cond_head_pose_sliding_window(model, ds, hp.to(dev), noise=nz, parents=parents,
-                                                                           window_offset=off, group=grp)
+                                                                           window_offset=off, group=grp, global_pairs=n)
             finally:
                 model.philox_seed = keep
     t_out = harness.output_frames(n_frames, seq_len)

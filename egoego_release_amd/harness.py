@@ -234,7 +234,7 @@ def output_frames(num_frames, seq_len):
 
 @torch.no_grad()
 def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos, global_head_jquat, cond_mask,
-                                             noise=None, parents=None, window_offset=0, group=None):
+                                             noise=None, parents=None, window_offset=0, group=None, global_pairs=None):
     """M:329-467.  Windows of `model.seq_len` frames, stride seq_len-10; window k+1 is conditioned on the
     last 10 frames of window k, re-canonicalised, by overwriting its first 10 frames after every step.
 
@@ -243,19 +243,22 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
     GLOBAL sequence index — what dist.harness_sharded uses so that the result does not depend on how sequences are sharded.
     group (dist.harness_sharded): the process group whose ranks sample from one plan (model.hip_engine / _outlier_guard are
     collective then); a rank without sequences (b = 0) walks the same collective calls and returns empty tensors.
+    global_pairs (dist.harness_sharded): the (sequence, sample) pairs of the WHOLE call over all ranks — the plan's small-job rule is
+    sized by the global job, so that the precision picked does not depend on how many ranks share it.
     """
     b = shape[0]
     S = model.num_timesteps
     seq_len = model.seq_len
     stride = seq_len - OVERLAP
     spans = window_spans(global_head_jpos.shape[1], seq_len)
-    job = (b * len(spans), seq_len, S)
+    job = ((b if global_pairs is None else int(global_pairs)) * len(spans), seq_len, S)
     eng = model.hip_engine(verify=True, job=job, group=group)
     device = model.betas.device
     if b == 0:
         empty = torch.zeros((0, seq_len, 198), device=device)
         for _ in spans:
             model._outlier_guard(eng, empty, empty, group=group)
+            eng = model.hip_engine()  # (a collective step-down re-packs here too: this rank must leave the int8 precision with the others)
         t_out = output_frames(global_head_jpos.shape[1], seq_len)
         return torch.zeros((0, t_out, 22, 3), device=device), torch.zeros((0, t_out, 3), device=device)
     parents = _parents_of(ds, parents)
@@ -332,21 +335,22 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
 
 @torch.no_grad()
 def sample_sliding_window_w_canonical(model, ds, global_head_jpos, global_head_jquat, x_start, cond_mask, noise=None,
-                                      parents=None, window_offset=0, group=None):
+                                      parents=None, window_offset=0, group=None, global_pairs=None):
     model.denoise_fn.eval()
     res = p_sample_loop_sliding_window_w_canonical(model, ds, x_start.shape, global_head_jpos, global_head_jquat,
-                                                   cond_mask, noise=noise, parents=parents, window_offset=window_offset, group=group)
+                                                   cond_mask, noise=noise, parents=parents, window_offset=window_offset, group=group,
+                                                   global_pairs=global_pairs)
     model.denoise_fn.train()
     return res
 
 
 @torch.no_grad()
-def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None, parents=None, window_offset=0, group=None):
+def full_body_gen_cond_head_pose_sliding_window(model, ds, head_pose, noise=None, parents=None, window_offset=0, group=None, global_pairs=None):
     """head_pose [B,T,7] = xyz + quaternion (w,x,y,z) -> (local axis-angle [B,T',22,3], root [B,T',3])."""
     jpos, jquat = head_pose[:, :, :3], head_pose[:, :, 3:]
     data = torch.zeros(head_pose.shape[0], head_pose.shape[1], 198, device=head_pose.device)
     return sample_sliding_window_w_canonical(model, ds, jpos, jquat, data, prep_head_condition_mask(data), noise=noise,
-                                             parents=parents, window_offset=window_offset, group=group)
+                                             parents=parents, window_offset=window_offset, group=group, global_pairs=global_pairs)
 
 
 # ------------------------------------------------------------------------------------------ checkpoints

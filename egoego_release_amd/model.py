@@ -153,7 +153,7 @@ class _EngineSlot:
     def __init__(self):
         self.engine, self.key, self.fingerprint = None, None, None
         self.engine_masked = None  # the context for padding-mask calls when the main one stores mean-shifted rows
-        self.plan = None       # what the context was packed from (_resolve_precision)
+        self.plan = None       # what the context was packed from (plan.resolve)
         self.ramp = None       # fingerprint weights (one per packed element)
         self.noise_buf = None  # scratch of the torch-RNG chain, reused across sample() calls
         self.envelope = None   # per LayerNorm site: the largest row maximum the pack-time probe has validated (runtime guard)
@@ -210,7 +210,7 @@ class CondGaussianDiffusion(nn.Module):
         # everywhere (~2e-5 on one forward on every checkpoint measured, ~85 % more time per step than 9).  The int8 precisions are
         # 16-bit FIXED point per row: what they lose depends on the checkpoint, so "auto" (default) is decided by MEASUREMENT and
         # remembered (plan.py): the ladder 9 as is -> 9 prepared -> 9 prepared + fc24 -> 8 as is -> 8 prepared -> 8 prepared + ffn16 -> 3, each candidate
-        # against split-bf16 on a probe batch (stage 1: the end of a chain + two forwards; stage 2: whole chains on 32 windows);
+        # against split-bf16 on a probe batch (stage 1: the end of a chain + two forwards; stage 2: whole chains on 128 windows);
         # the verdict is cached on disk per checkpoint; a chain-level call shorter than the probe runs split-bf16 unprobed; under
         # torch.distributed the sharded entry points (dist.py) make all ranks pack rank 0's plan.  `hip_precision_used` /
         # `hip_precision_probe` tell what was picked, from where ("probe" / "cache" / "small job" / "group rank 0 (...)"), and what
@@ -333,8 +333,17 @@ class CondGaussianDiffusion(nn.Module):
                 raise ValueError(f"unknown objective {self.objective}")
             if synced:
                 import torch.distributed as tdist
-                plan = plan_mod.resolve(self, job, fp) if tdist.get_rank(group) == 0 else None
+                plan, failure = None, None
+                if tdist.get_rank(group) == 0:
+                    try:
+                        plan = plan_mod.resolve(self, job, fp)
+                    except Exception as e:  # (out of memory in the probe, ...: the peers wait in the broadcast and must hear about it)
+                        failure, plan = e, {"error": repr(e)}
                 plan = plan_mod.group_broadcast(plan, group)
+                if "error" in plan:
+                    if failure is not None:
+                        raise failure
+                    raise _lib.EgoEgoHipError(f"group rank 0 failed while resolving the precision plan: {plan['error']}")
                 plan = dict(plan, source=plan["source"] if tdist.get_rank(group) == 0 else f"group rank 0 ({plan['source']})")
             else:
                 plan = plan_mod.resolve(self, job, fp)
@@ -373,18 +382,26 @@ class CondGaussianDiffusion(nn.Module):
         group (dist.py): the decision is COLLECTIVE — the row maxima are all-reduced (MAX) over the ranks, group rank 0 (which holds
         the global batch's first windows, like a single rank would) re-measures, and its verdict is broadcast: every rank steps
         down, or none does.  Every rank of the group must call this, with an empty shard too."""
-        if not self.hip_outlier_guard or self.hip_precision_used not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
-            return
         synced = group is not None and _world(group) > 1
-        if x.shape[0] == 0 and not synced:
+        active = bool(self.hip_outlier_guard) and self.hip_precision_used in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC)
+        if not synced and (not active or x.shape[0] == 0):
             return
         n_sites = min(_lib.OUTLIER_SITES, 2 * self.denoise_fn.n_dec_layers)
-        seen = eng.outlier_stats(x.shape[0], x.shape[1], reset=True) if x.shape[0] else [0.0] * n_sites
-        if synced:
-            seen = plan_mod.group_max(seen, group)
-        self.hip_outlier_seen = seen
+        seen = eng.outlier_stats(x.shape[0], x.shape[1], reset=True) if (active and x.shape[0]) else [0.0] * n_sites
         env = self._slot.envelope
-        lim = [self.ENVELOPE_ABSOLUTE] * len(seen) if env is None else [self.ENVELOPE_MARGIN * max(v, 1e-30) for v in env]
+        lim = [self.ENVELOPE_ABSOLUTE] * n_sites if env is None else [self.ENVELOPE_MARGIN * max(v, 1e-30) for v in env]
+        if synced:
+            # ONE all_reduce carries everything the decision depends on, so every rank takes the same branch whatever its local
+            # state: the row maxima (MAX), the limits (MIN, as MAX of the negatives: a rank whose envelope grew in an unsharded
+            # call in between does not leave alone), and whether any / every rank is running an int8 precision with the guard on
+            got = plan_mod.group_max(list(seen) + [-v for v in lim] + [1.0 if active else 0.0, 0.0 if active else 1.0], group)
+            seen, lim = got[:n_sites], [-v for v in got[n_sites:2 * n_sites]]
+            if got[-2] > 0 and got[-1] > 0:
+                raise _lib.EgoEgoHipError("the ranks of the process group sample in different precisions (some int8 with the runtime guard, some not): "
+                                          "pack through the sharded entry points (dist.py) with verify=True so that all ranks hold one plan")
+            if got[-2] == 0:
+                return
+        self.hip_outlier_seen = seen
         if all(s <= l for s, l in zip(seen, lim)):
             return
         prec, plan = self.hip_precision_used, self._slot.plan
@@ -392,21 +409,30 @@ class CondGaussianDiffusion(nn.Module):
         if synced:
             import torch.distributed as tdist
             measure = tdist.get_rank(group) == 0
-        ok, err = True, 0.0
+        ok, err, failure = True, 0.0, None
         if measure and x.shape[0]:
-            n = min(int(x.shape[0]), 8)
-            probe = PrecisionProbe(self, probe=(x[:n], x_cond[:n]), tail=self.PROBE_TAIL)
             try:
-                psd = plan["sd"] if plan["sd"] is not None else probe.sd
-                err, _ = probe.error(psd, prec, plan["row_shift"], plan["flags"])
-                ok = err <= self.PROBE_LIMIT
-                if ok and self.hip_probe_full_chain:
-                    err, _ = probe.chain_error(psd, prec, plan["row_shift"], plan["flags"])
-                    ok = err <= self.CHAIN_LIMIT
-            finally:
-                probe.close()
+                n = min(int(x.shape[0]), 8)
+                probe = PrecisionProbe(self, probe=(x[:n], x_cond[:n]), tail=self.PROBE_TAIL)
+                try:
+                    psd = plan["sd"] if plan["sd"] is not None else probe.sd
+                    err, _ = probe.error(psd, prec, plan["row_shift"], plan["flags"])
+                    ok = err <= self.PROBE_LIMIT
+                    if ok and self.hip_probe_full_chain:
+                        err, _ = probe.chain_error(psd, prec, plan["row_shift"], plan["flags"])
+                        ok = err <= self.CHAIN_LIMIT
+                finally:
+                    probe.close()
+            except Exception as e:  # (the peers wait in the broadcast below: they must hear about it)
+                if not synced:
+                    raise
+                failure = e
         if synced:
-            ok, err = plan_mod.group_broadcast((ok, err), group)
+            ok, err, msg = plan_mod.group_broadcast((ok, err, None if failure is None else repr(failure)), group)
+            if msg is not None:
+                if failure is not None:
+                    raise failure
+                raise _lib.EgoEgoHipError(f"group rank 0 failed while re-measuring the precision: {msg}")
         if ok:
             self._slot.envelope = [max(a, b) for a, b in zip(seen, env)] if env is not None else list(seen)
             return
@@ -416,6 +442,7 @@ class CondGaussianDiffusion(nn.Module):
                f"{prec} differs from split-bf16 by {err:.1e} on this chain's own tensors (limits {self.PROBE_LIMIT:.0e} / {self.CHAIN_LIMIT:.1e})")
         if self.hip_precision == "auto":
             self._slot.demoted = self._slot.force_repack = True  # re-pack at the next call
+            plan_mod.cache_drop(self._slot.plan.get("cache_key") if self._slot.plan else None)  # (a later process must not start from the int8 verdict again)
             warnings.warn(msg + ": hip_precision='auto' uses split-bf16 (3) from the next call on", RuntimeWarning, stacklevel=4)
         else:
             warnings.warn(msg + f": hip_precision={prec} was set explicitly and is kept", RuntimeWarning, stacklevel=4)

@@ -212,11 +212,28 @@ def cache_load(key):
     if not os.path.exists(path):
         return None
     try:
-        plan = torch.load(path, map_location="cpu", weights_only=False)
+        # weights_only: a plan holds dicts, tuples, lists, strings, numbers and tensors — nothing that needs the full unpickler
+        # (a writable cache directory must not mean code execution at pack time)
+        plan = torch.load(path, map_location="cpu", weights_only=True)
         assert isinstance(plan, dict) and "precision" in plan
+        os.utime(path)  # (recently used: cache_store evicts the oldest)
     except Exception:
-        return None  # unreadable / half-written by another process: measure again
+        return None  # unreadable / half-written by another process / written by something else: measure again
     return plan
+
+
+CACHE_MAX_FILES = 16  # a plan of a prepared form carries a full state dict (~45 MB): e.g. periodic EMA evaluations during training would pile them up
+
+
+def cache_drop(key):
+    """Forget a verdict (the runtime guard stepped `auto` down on live tensors: the next process must measure again)."""
+    d = cache_dir()
+    if d is None or key is None:
+        return
+    try:
+        os.remove(os.path.join(d, f"plan_{key}.pt"))
+    except OSError:
+        pass
 
 
 def cache_store(key, plan):
@@ -229,6 +246,9 @@ def cache_store(key, plan):
         os.close(fd)
         torch.save(_to_cpu(plan), tmp)
         os.replace(tmp, os.path.join(d, f"plan_{key}.pt"))  # atomic: a reader sees the old file or the whole new one
+        old = sorted((os.path.join(d, f) for f in os.listdir(d) if f.startswith("plan_") and f.endswith(".pt")), key=os.path.getmtime)
+        for path in old[:-CACHE_MAX_FILES]:
+            os.remove(path)
     except OSError:
         pass  # a read-only home: the verdict is simply not remembered
 
@@ -256,7 +276,7 @@ def resolve(model, job=None, fingerprint=None):
         key = cache_key(model, fingerprint if fingerprint is not None else model._weights_fingerprint())
         hit = cache_load(key)
         if hit is not None:
-            return dict(hit, source="cache")
+            return dict(hit, source="cache", cache_key=key)
     if is_small_job(model, job):
         return plain_plan(_lib.PREC_BF16X3, "small job",
                           {"skipped": f"a job of {job[0]} windows x {job[2]} steps is shorter than the precision probe: split-bf16 (no verdict "
@@ -264,6 +284,7 @@ def resolve(model, job=None, fingerprint=None):
     plan = run_ladder(model)
     if key is not None:
         cache_store(key, plan)
+        plan["cache_key"] = key
     return plan
 
 

@@ -10,6 +10,8 @@ import torch.multiprocessing as mp
 
 from egoego_release_amd import dist as D
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_shard_bounds_cover_everything():
     for n in (1, 2, 7, 256, 257):
@@ -332,3 +334,58 @@ def test_all_ranks_sample_from_one_plan_and_step_down_together(tmp_path):
     if one["plan"][3]:
         assert r0["w_sum"] == r1["w_sum"] == one["w_sum"]
     assert torch.equal(r0["third"], one["third"]) and torch.equal(r1["third"], one["third"])
+
+
+# ------------------------------------------------------------------------------------------ a rank without pairs and a guard trip
+def _empty_rank_run(rank, world, out):
+    """harness_sharded with ONE (sequence, sample) pair on `world` ranks — rank 1 holds nothing — over the demo trajectory's two windows,
+    on a checkpoint whose LayerNorm monitors trip the runtime guard at the end of window 0: every rank re-packs in split-bf16 before
+    window 1, the empty one included (left on precision 9 it would enter the next guard's collective alone)."""
+    import warnings
+    import numpy as np
+    from egoego_release_amd import harness
+    from egoego_release_amd.model import CondGaussianDiffusion
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_harness_golden import REST_OFFSETS
+    torch.cuda.set_device(0)
+    hg = np.load(os.path.join(ROOT, "tests", "golden", "harness_golden.npz"))
+    ds = harness.SkeletonStats(hg["stats_global_jpos_min"], hg["stats_global_jpos_max"], REST_OFFSETS)
+    cfg, sd = _massive_feature_weights()
+    m = CondGaussianDiffusion(**cfg.ctor_kwargs())
+    m.load_state_dict(sd, strict=False)
+    m.hip_probe_at_pack = False  # "auto" starts on precision 9 with the absolute envelope
+    m = m.cuda()
+    m.num_timesteps = 5
+    head_pose = torch.from_numpy(hg["demo_head_qpos"]).float()[None]
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        aa, root = D.harness_sharded(m, ds, head_pose, sample_bs=1, seed=5)
+    torch.save({"aa": aa.cpu(), "root": root.cpu(), "prec": int(m.hip_precision_used), "demoted": bool(m._slot.demoted),
+                "warned": any("beyond what the pack-time probe validated" in str(w.message) for w in rec)}, out + str(rank))
+
+
+def _empty_rank_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    _empty_rank_run(rank, world, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_harness_rank_without_pairs_steps_down_with_the_others(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out2, out1 = str(tmp_path / "two_"), str(tmp_path / "one_")
+    mp.spawn(_empty_rank_worker, args=(2, port, out2), nprocs=2, join=True)
+    _empty_rank_run(0, 1, out1)
+    one, r0, r1 = torch.load(out1 + "0"), torch.load(out2 + "0"), torch.load(out2 + "1")
+    assert one["demoted"] and one["prec"] == 3
+    assert r0["demoted"] and r0["warned"] and r0["prec"] == 3
+    assert r1["demoted"] and r1["prec"] == 3  # the rank without pairs left precision 9 together with rank 0
+    for r in (r0, r1):
+        assert r["aa"].shape == (1, 140, 22, 3) and torch.equal(r["aa"], one["aa"]) and torch.equal(r["root"], one["root"])

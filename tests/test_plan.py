@@ -217,3 +217,56 @@ def test_ladder_decisions_with_a_scripted_probe(monkeypatch):
     p = plan.run_ladder(m)
     assert (p["precision"], p["form"]) == (8, "prepared + ffn16") and p["probe"]["errors"]["8 prepared + ffn16, amplification"] == 2e-3 / 1e-4
     assert A == 3.0 and C == 6.0e-4 and plan.CHAIN_WINDOWS == 128  # (the figures DESIGN.md 3c derives)
+
+
+def test_harness_sizes_its_plan_by_the_global_job(tmp_path, monkeypatch):
+    """under dist.harness_sharded the small-job rule must see the WHOLE call's (sequence, sample) pairs, not this rank's shard —
+    else two ranks with 5 pairs each run split-bf16 unprobed where one rank with 10 measures and picks an int8 form.  Both sides of the
+    threshold, empty cache: 10 pairs x 2 windows x 1000 steps is a measured job, a 5-pair call of its own is a small one."""
+    import pytest
+    from egoego_release_amd import harness
+    monkeypatch.setenv("EGOEGO_HIP_CACHE", str(tmp_path))
+    m = CondGaussianDiffusion(**ModelConfig(max_timesteps=121).ctor_kwargs())
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_engine(verify=False, masked=False, job=None, group=None):
+        seen["job"] = job
+        raise Stop()
+    m.hip_engine = fake_engine
+    ds = harness.SkeletonStats(-torch.ones(66), torch.ones(66), torch.zeros(66))
+    head = torch.zeros(5, 140, 7)
+    head[..., 3] = 1.0
+    with pytest.raises(Stop):
+        harness.full_body_gen_cond_head_pose_sliding_window(m, ds, head, global_pairs=10)
+    assert seen["job"] == (10 * 2, 120, 1000) and not plan.is_small_job(m, seen["job"])
+    with pytest.raises(Stop):
+        harness.full_body_gen_cond_head_pose_sliding_window(m, ds, head)
+    assert seen["job"] == (5 * 2, 120, 1000) and plan.is_small_job(m, seen["job"])
+    # dist.harness_sharded hands the global count over (one process: its shard is everything; sample_bs multiplies the pairs)
+    with pytest.raises(Stop):
+        D.harness_sharded(m, ds, head[:2], sample_bs=3)
+    assert seen["job"] == (6 * 2, 120, 1000)
+
+
+def test_cache_is_loaded_without_the_full_unpickler_and_evicted(tmp_path, monkeypatch):
+    """plans are read with weights_only=True (a writable cache directory must not mean code execution), a file that needs
+    the full unpickler reads as a miss, the oldest files beyond CACHE_MAX_FILES go, and cache_drop forgets a verdict."""
+    monkeypatch.setenv("EGOEGO_HIP_CACHE", str(tmp_path))
+    p = dict(plan.plain_plan(9, "probe"), sd={"w": torch.ones(2)}, row_shift={"embed": torch.zeros(2), (0, "attn_ln"): torch.ones(2)}, envelope=[1.0, 2.0])
+    plan.cache_store("k0", p)
+    got = plan.cache_load("k0")
+    assert got["precision"] == 9 and torch.equal(got["row_shift"][(0, "attn_ln")], torch.ones(2)) and got["envelope"] == [1.0, 2.0]
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    torch.save({"precision": 9, "x": Evil()}, os.path.join(str(tmp_path), "plan_evil.pt"))
+    assert plan.cache_load("evil") is None
+    for i in range(plan.CACHE_MAX_FILES + 3):
+        plan.cache_store(f"n{i}", p)
+    assert len([f for f in os.listdir(str(tmp_path)) if f.startswith("plan_")]) <= plan.CACHE_MAX_FILES
+    plan.cache_drop(f"n{plan.CACHE_MAX_FILES + 2}")
+    assert plan.cache_load(f"n{plan.CACHE_MAX_FILES + 2}") is None
