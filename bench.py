@@ -91,6 +91,104 @@ def cpu_baseline(cfg, sd, B, T, budget_s=25.0):
             "ms_per_step": 1e3 * el / n}
 
 
+def kernel_launch_times(eng, x_l, xc_l, t_start, n_steps, lo):
+    """Average launch duration (us) of the attention-layer and layer-tail launch sites over `n_steps` extra steps, by HIP event pairs around
+    every launch of that site on the launch stream (egoego_profile_begin / _end): {"qkv": (us, launches), "fc_ln": (us, launches)}."""
+    import torch
+    from egoego_release_amd import _lib
+    kern = {"qkv": (0.0, 0), "fc_ln": (0.0, 0)}
+    for name in (("qkv", "fc_ln") if x_l.shape[0] else ()):  # (a rank can be empty when there are fewer windows than ranks)
+        eng.profile_begin(name)
+        eng.sample_loop_(x_l, xc_l, t_start, n_steps, noise_mode=_lib.NOISE_PHILOX, seed=7, window_offset=lo)
+        torch.cuda.synchronize()
+        kern[name] = eng.profile_end()
+    return kern
+
+
+def load_traffic(Bl, T, prec, weights):
+    """HBM bytes per launch per kernel from the separate rocprofv3 --pmc passes of this command summarised under profiles/ (newest round
+    first; `rNN_traffic.json` = precision 9, `rNN_traffic_p3.json` = split-bf16) -> ({kernel: {...}}, source) or ({}, None)."""
+    import glob
+    try:
+        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+            with open(tp) as f:
+                tj = json.load(f)
+            if (Bl, T, prec) == (tj.get("batch"), tj.get("window"), tj.get("precision")) and tj.get("weights", "synthetic") in (weights, "any"):
+                return tj["kernels"], f"profiles/{os.path.basename(tp)} (rocprofv3 --pmc passes of this command; not measured in this run)"
+    except Exception:
+        pass
+    return {}, None
+
+
+def roofline_objects(eng, prec, Bl, T, kern, ms_step, traffic, traffic_src):
+    """(dominant, other): the roofline objects of the attention-layer and the layer-tail kernel — algorithmic operations per launch over
+    the HIP-event launch time, against the peak of the MFMAs the kernel issues."""
+    L = T + 1
+    (k_us, k_n), (t_us, t_n) = kern["qkv"], kern["fc_ln"]
+    if True:
+        # which kernels ran comes from the library (egoego_last_kernel_name: it records what its dispatch picked for this shape and
+        # precision during the profiled steps above) — no copy of the dispatch rules here
+        attn_full, tail_full = eng.last_kernel("qkv"), eng.last_kernel("fc_ln")
+        attn_name, tail_name = attn_full.split("<")[0], tail_full.split("<")[0]
+        i8_layer = attn_name in ("attn_layer_i8w_kernel", "attn_layer_i8h_kernel", "attn_proj_i8_kernel", "attn_proj6_i8_kernel")
+        i8_long = attn_name == "qkv_i8q_kernel"
+        o8 = prec == 9 and L > 64                      # the attention kernels hand O over as int8 rows (2 B per value)
+        ATTN_TXT = {
+            "attn_layer_i8w_kernel": "Q/K/V projections, softmax and PV of one window x head per 8-wave workgroup, int8 slices; K, V, Q and the probabilities stay in LDS/registers",
+            "attn_layer_i8h_kernel": "the one-kernel int8 attention layer as two half-query workgroups per window x head (small grids)",
+            "attn_proj_i8_kernel": "Q/K/V projections of a window x head as three workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
+            "attn_proj6_i8_kernel": "Q/K/V projections of a window x head as six workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
+            "qkv_i8q_kernel": "Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8w_kernel; projection operations only",
+            "qkv_i8_kernel": "Q/K/V projections on int8 slices for the split-bf16 attention core; projection operations only",
+            "qkv_attn_kernel": "fused Q/K/V projection + attention, split-bf16",
+            "qkv_kernel": "Q/K/V projections, split-bf16; projection operations only"}
+        proj_only = attn_name not in ("attn_layer_i8w_kernel", "attn_layer_i8h_kernel", "qkv_attn_kernel")
+        attn_i8 = i8_layer or i8_long or attn_name == "qkv_i8_kernel"
+        attn_peak = PEAK_I8_TOPS if attn_i8 else PEAK_BF16_TFLOPS
+        attn_flops = Bl * 2 * L * 512 * 3 * 1024 if proj_only else qkv_attn_flops_per_launch(Bl, T)
+        attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None
+        tail_ach = tail_flops_per_launch(Bl, T) / (t_us * 1e-6) / 1e12 if t_n else None
+        # algorithmic HBM bytes of one attention-layer launch: the layer input rows in (int8 slices: 2 B per value; split-bf16: 4),
+        # O out (int8 rows with precision 9: 2 B per value; split-bf16: 4) + the three projections' weights once
+        attn_bytes = ((2 if attn_i8 else 4) * Bl * L * 512 + (2 if o8 else 4) * Bl * L * 1024 + (2 if attn_i8 else 4) * 3 * 512 * 1024) if not proj_only else None
+        core_flops = Bl * 4 * L * L * 1024  # QK^T + PV: what north_star words as the "attention-GEMM roofline"
+        attn_roof = {
+            "bound": "mfma", "kernel": f"{attn_full} ({ATTN_TXT.get(attn_name, '')})",
+            "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if attn_i8 else "TFLOP/s",
+            "frac": (attn_ach / attn_peak) if attn_ach else None,
+            "traffic": (traffic.get(attn_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
+            "algorithmic_bytes": attn_bytes,
+            "launch_us": k_us, "launches": k_n, "share_of_step": 4 * k_us / (1e3 * ms_step) if k_n else None,
+            "attention_core_share_of_operations": None if proj_only else core_flops / attn_flops,
+            "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time, measured on rank 0's shard right after "
+                    "the timed region; three MFMAs are issued per product (two int8 slices / two bf16 planes per operand), so matrix-pipe "
+                    "utilisation is 3x this fraction.  The kernel is one launch for projections + QK^T + softmax + PV: the attention "
+                    "core alone (QK^T + PV) is `attention_core_share_of_operations` of its operations and has no launch time of its own"}
+        fc8 = prec == 9 and L > 64
+        TAIL_TXT = {
+            "tail_kernel": "fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 32/64 tokens: weights streamed into registers, activations by "
+                           "LDS-DMA chunks (precision 9: all three contractions on int8 slices, one integer chain per head in fc, LayerNorm-1 rows and hidden rows resident in LDS)",
+            "layer_tail_i8_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands; fc split-bf16, FFN on int8 slices in two passes into one int32 accumulator",
+            "layer_tail_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands, split-bf16",
+            "layer_tail_kernel:128": "the same three GEMMs per 128 tokens, one eight-wave workgroup per CU, LDS-ring operands, split-bf16",
+            "gemm_kernel:EpiResLN": "fc + residual + LayerNorm alone (unfused small-batch form; FFN-1 / FFN-2 are separate launches not in this figure)"}
+        # the peak of the MFMAs the kernel issues: all int8 (precision 9), fc bf16 + FFN int8 (precision 8: the two halves of its
+        # FLOPs at 2.5 and 5 P, i.e. 3333 T together), all bf16 (precisions 3, 1)
+        tail_peak = PEAK_I8_TOPS if fc8 else (2.0 / (1.0 / PEAK_BF16_TFLOPS + 1.0 / PEAK_I8_TOPS) if prec == 8 else PEAK_BF16_TFLOPS)
+        tail_unit = "TOP/s (int8 MFMA, 2 per MAC)" if fc8 else ("TFLOP/s (fc on bf16 MFMAs, FFN on int8 MFMAs)" if prec == 8 else "TFLOP/s")
+        tail_roof = {
+            "bound": "mfma", "kernel": f"{tail_full} ({TAIL_TXT.get(tail_name, '')})",
+            "achieved": tail_ach, "peak": tail_peak, "unit": tail_unit, "frac": (tail_ach / tail_peak) if tail_ach else None,
+            "traffic": (traffic.get(tail_full) or traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
+            # precision 9: the attention output (1024 x 2 B), the residual rows in and the layer's rows out (512 x 2 B each) per token
+            # + the int8 weights once; the other precisions: split-bf16 rows (4 B per value) incl. the hidden activations
+            "algorithmic_bytes": (2 * Bl * L * (1024 + 512 + 512) + 2.1e6) if fc8 else (4 * Bl * L * (1024 + 512 + 512) + 4.2e6),
+            "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * ms_step) if t_n else None,
+            "note": "measured like the attention-layer kernel; 3 MFMAs are issued per product (split-bf16: K=16 per MFMA; int8 slices: K=32 per "
+                    "MFMA at the same issue time); normalised by the peak of the MFMAs the kernel actually issues"}
+    return (attn_roof, tail_roof) if (k_us or 0) >= (t_us or 0) else (tail_roof, attn_roof)
+
+
 def trained_like_line(args, cfg, dev, B, T, K, W):
     """The same timed region (K graph-replayed steps after W warm-up steps, inputs resident) on a TRAINED-LIKE checkpoint — the
     module's own training loss optimised for --train-steps Adam steps on synthetic motion, on this GPU, right here
@@ -128,10 +226,23 @@ def trained_like_line(args, cfg, dev, B, T, K, W):
     D.sample_local(timed_fn, xs, cm, noise)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    guarded_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7)  # (the same steps with the checksum and the runtime guard's read-back, like a caller's chain)
+    tg = time.perf_counter()
+    D.sample_local(guarded_fn, xs, cm, noise)
+    torch.cuda.synchronize()
+    ms_guarded = 1e3 * (time.perf_counter() - tg) / K
     eng = model.hip_engine()
+    prec = int(model.hip_precision_used)
+    x_l = noise["x_T"].contiguous().clone()
+    xc_l = (xs * (1 - cm) + cm * noise["cond"]).contiguous()
+    kern = kernel_launch_times(eng, x_l, xc_l, S - 1 - W, min(K, 20), 0)
+    traffic, traffic_src = load_traffic(B, T, prec, "any")
+    dominant, other = roofline_objects(eng, prec, B, T, kern, 1e3 * el / K, traffic, traffic_src)
     probe = model.hip_precision_probe or {}
-    return {"precision": int(model.hip_precision_used), "form": probe.get("form"), "plan_source": probe.get("source"),
-            "ms_per_step": 1e3 * el / K, "steps_per_s": K / el, "steps": K, "warmup": W,
+    return {"precision": prec, "form": probe.get("form"), "plan_source": probe.get("source"),
+            "ms_per_step": 1e3 * el / K, "steps_per_s": K / el, "steps": K, "warmup": W, "ms_per_step_with_checksum_and_guard": ms_guarded,
+            "step_frac_of_bf16_peak": flops_per_window_step(T) * B * K / el / 1e12 / PEAK_BF16_TFLOPS,
+            "roofline": dominant, "roofline_second_kernel": other,
             "probe_errors": probe.get("errors"), "probe_limits": {"stage1": probe.get("limit"), "whole_chain": probe.get("chain_limit"),
                                                                   "chain_windows": probe.get("chain_windows")},
             "attention_kernel": eng.last_kernel("qkv"), "tail_kernel": eng.last_kernel("fc_ln"),
@@ -168,8 +279,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="GLOBAL number of windows (split over the GPUs)")
     ap.add_argument("--window", type=int, default=120)
     ap.add_argument("--precision", default="auto", choices=("auto", "1", "3", "8", "9"),
-                    help="auto (default) = what the module's default picks for these weights by measuring them (model.py _resolve_precision: "
-                         "9, else 8, else 3); 9 = int8-slice attention layer, fc, FFN and linear_out + split-bf16 embed (parity-grade, the "
+                    help="auto (default) = what the module's default picks for these weights by measuring them (plan.py: the ladder "
+                         "9 ... 8 ... 3); 9 = int8-slice attention layer, fc, FFN and linear_out + split-bf16 embed (parity-grade, the "
                          "fastest mode inside the 1e-3 bar), 8 = the same with fc / linear_out on split-bf16 (parity-grade, half the error), "
                          "3 = split-bf16 everywhere (parity-grade), 1 = plain bf16 (NOT parity-grade)")
     ap.add_argument("--weights", default="synthetic", choices=("synthetic", "trained-like"),
@@ -292,6 +403,14 @@ def main():
     if args.dump and rank == 0:
         torch.save(out.cpu(), args.dump)
 
+    # the product path as a caller runs it — weights checksummed, plan agreed on, the runtime guard's read-back at the end of the chain —
+    # timed next to the bare region (the headline's timed call does none of the three)
+    guarded_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7)
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    D.sample_local(guarded_fn, xs, cm, noise)
+    torch.cuda.synchronize()
+    ms_step_guarded = 1e3 * (time.perf_counter() - tg) / K
     # per-kernel launch durations (HIP events on the launch stream), measured AFTER the timed region on this rank's
     # shard: a few extra steps per kernel with event pairs around every launch of that kernel
     Bl = hi - lo
@@ -299,95 +418,14 @@ def main():
     guard_demoted = int(model.hip_precision_used) != prec
     x_l = noise["x_T"][lo:hi].contiguous().clone()
     xc_l = (xs[lo:hi] * (1 - cm[lo:hi]) + cm[lo:hi] * noise["cond"][lo:hi]).contiguous()
-    kern = {"qkv": (0.0, 0), "fc_ln": (0.0, 0)}
-    for name in (("qkv", "fc_ln") if Bl else ()):  # (a rank can be empty when there are fewer windows than ranks)
-        eng.profile_begin(name)
-        eng.sample_loop_(x_l, xc_l, S - 1 - W, min(K, 20), noise_mode=_lib.NOISE_PHILOX, seed=7, window_offset=lo)
-        torch.cuda.synchronize()
-        kern[name] = eng.profile_end()
-    (k_us, k_n), (t_us, t_n) = kern["qkv"], kern["fc_ln"]
-
-    traffic, traffic_src = {}, None
-    try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command, summarised under profiles/
-        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
-            tp = os.path.join(ROOT, "profiles", name)
-            if not os.path.exists(tp):
-                continue
-            with open(tp) as f:
-                tj = json.load(f)
-            if (Bl, T, prec) == (tj.get("batch"), tj.get("window"), tj.get("precision")) and tj.get("weights", "synthetic") == args.weights:
-                traffic = tj["kernels"]
-                traffic_src = f"profiles/{name} (rocprofv3 --pmc passes of this command; not measured in this run)"
-                break
-    except Exception:
-        traffic = {}
+    kern = kernel_launch_times(eng, x_l, xc_l, S - 1 - W, min(K, 20), lo)
+    traffic, traffic_src = load_traffic(Bl, T, int(model.hip_precision_used), args.weights)
 
     if rank == 0:
         steps_per_s = K / el
         fl_step = flops_per_window_step(T) * B
-        L = T + 1
         ms_step = 1e3 * el / K
-        # which kernels ran comes from the library (egoego_last_kernel_name: it records what its dispatch picked for this shape and
-        # precision during the profiled steps above) — no copy of the dispatch rules here
-        attn_full, tail_full = eng.last_kernel("qkv"), eng.last_kernel("fc_ln")
-        attn_name, tail_name = attn_full.split("<")[0], tail_full.split("<")[0]
-        i8_layer = attn_name in ("attn_layer_i8w_kernel", "attn_layer_i8h_kernel", "attn_proj_i8_kernel", "attn_proj6_i8_kernel")
-        i8_long = attn_name == "qkv_i8q_kernel"
-        o8 = prec == 9 and L > 64                      # the attention kernels hand O over as int8 rows (2 B per value)
-        ATTN_TXT = {
-            "attn_layer_i8w_kernel": "Q/K/V projections, softmax and PV of one window x head per 8-wave workgroup, int8 slices; K, V, Q and the probabilities stay in LDS/registers",
-            "attn_layer_i8h_kernel": "the one-kernel int8 attention layer as two half-query workgroups per window x head (small grids)",
-            "attn_proj_i8_kernel": "Q/K/V projections of a window x head as three workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
-            "attn_proj6_i8_kernel": "Q/K/V projections of a window x head as six workgroups writing int8 images (+ attn_core_s_kernel, not in this figure); projection operations only",
-            "qkv_i8q_kernel": "Q/K/V projections on int8 slices, quantised into the int8 operand images of attn_core_i8w_kernel; projection operations only",
-            "qkv_i8_kernel": "Q/K/V projections on int8 slices for the split-bf16 attention core; projection operations only",
-            "qkv_attn_kernel": "fused Q/K/V projection + attention, split-bf16",
-            "qkv_kernel": "Q/K/V projections, split-bf16; projection operations only"}
-        proj_only = attn_name not in ("attn_layer_i8w_kernel", "attn_layer_i8h_kernel", "qkv_attn_kernel")
-        attn_i8 = i8_layer or i8_long or attn_name == "qkv_i8_kernel"
-        attn_peak = PEAK_I8_TOPS if attn_i8 else PEAK_BF16_TFLOPS
-        attn_flops = Bl * 2 * L * 512 * 3 * 1024 if proj_only else qkv_attn_flops_per_launch(Bl, T)
-        attn_ach = attn_flops / (k_us * 1e-6) / 1e12 if k_n else None
-        tail_ach = tail_flops_per_launch(Bl, T) / (t_us * 1e-6) / 1e12 if t_n else None
-        # algorithmic HBM bytes of one attention-layer launch: the layer input rows in (int8 slices: 2 B per value; split-bf16: 4),
-        # O out (int8 rows with precision 9: 2 B per value; split-bf16: 4) + the three projections' weights once
-        attn_bytes = ((2 if attn_i8 else 4) * Bl * L * 512 + (2 if o8 else 4) * Bl * L * 1024 + (2 if attn_i8 else 4) * 3 * 512 * 1024) if not proj_only else None
-        core_flops = Bl * 4 * L * L * 1024  # QK^T + PV: what north_star words as the "attention-GEMM roofline"
-        attn_roof = {
-            "bound": "mfma", "kernel": f"{attn_full} ({ATTN_TXT.get(attn_name, '')})",
-            "achieved": attn_ach, "peak": attn_peak, "unit": "TOP/s (int8 MFMA, 2 per MAC)" if attn_i8 else "TFLOP/s",
-            "frac": (attn_ach / attn_peak) if attn_ach else None,
-            "traffic": (traffic.get(attn_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
-            "algorithmic_bytes": attn_bytes,
-            "launch_us": k_us, "launches": k_n, "share_of_step": 4 * k_us / (1e3 * ms_step) if k_n else None,
-            "attention_core_share_of_operations": None if proj_only else core_flops / attn_flops,
-            "note": "algorithmic operations (one per MAC x 2) over the HIP-event launch time, measured on rank 0's shard right after "
-                    "the timed region; three MFMAs are issued per product (two 8-bit slices per operand), so matrix-pipe "
-                    "utilisation is 3x this fraction.  The kernel is one launch for projections + QK^T + softmax + PV: the attention "
-                    "core alone (QK^T + PV) is `attention_core_share_of_operations` of its operations and has no launch time of its own"}
-        fc8 = prec == 9 and L > 64
-        TAIL_TXT = {
-            "tail_kernel": "fc+residual+LayerNorm -> FFN-1 -> FFN-2+residual+LayerNorm per 32/64 tokens: weights streamed into registers, activations by "
-                           "LDS-DMA chunks (precision 9: all three contractions on int8 slices, one integer chain per head in fc, LayerNorm-1 rows and hidden rows resident in LDS)",
-            "layer_tail_i8_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands; fc split-bf16, FFN on int8 slices in two passes into one int32 accumulator",
-            "layer_tail_kernel": "the same three GEMMs per 64 tokens, two workgroups per CU, LDS-ring operands, split-bf16",
-            "layer_tail_kernel:128": "the same three GEMMs per 128 tokens, one eight-wave workgroup per CU, LDS-ring operands, split-bf16",
-            "gemm_kernel:EpiResLN": "fc + residual + LayerNorm alone (unfused small-batch form; FFN-1 / FFN-2 are separate launches not in this figure)"}
-        # the peak of the MFMAs the kernel issues: all int8 (precision 9), fc bf16 + FFN int8 (precision 8: the two halves of its
-        # FLOPs at 2.5 and 5 P, i.e. 3333 T together), all bf16 (precisions 3, 1)
-        tail_peak = PEAK_I8_TOPS if fc8 else (2.0 / (1.0 / PEAK_BF16_TFLOPS + 1.0 / PEAK_I8_TOPS) if prec == 8 else PEAK_BF16_TFLOPS)
-        tail_unit = "TOP/s (int8 MFMA, 2 per MAC)" if fc8 else ("TFLOP/s (fc on bf16 MFMAs, FFN on int8 MFMAs)" if prec == 8 else "TFLOP/s")
-        tail_roof = {
-            "bound": "mfma", "kernel": f"{tail_full} ({TAIL_TXT.get(tail_name, '')})",
-            "achieved": tail_ach, "peak": tail_peak, "unit": tail_unit, "frac": (tail_ach / tail_peak) if tail_ach else None,
-            "traffic": (traffic.get(tail_full) or traffic.get(tail_name) or {}).get("hbm_bytes_per_launch"), "traffic_source": traffic_src,
-            # precision 9: the attention output (1024 x 2 B), the residual rows in and the layer's rows out (512 x 2 B each) per token
-            # + the int8 weights once; the other precisions: split-bf16 rows (4 B per value) incl. the hidden activations
-            "algorithmic_bytes": (2 * Bl * L * (1024 + 512 + 512) + 2.1e6) if fc8 else (4 * Bl * L * (1024 + 512 + 512) + 4.2e6),
-            "launch_us": t_us, "launches": t_n, "share_of_step": 4 * t_us / (1e3 * ms_step) if t_n else None,
-            "note": "measured like the attention-layer kernel; 3 MFMAs are issued per product (split-bf16: K=16 per MFMA; int8 slices: K=32 per "
-                    "MFMA at the same issue time); normalised by the peak of the MFMAs the kernel actually issues"}
-        dominant, other = (attn_roof, tail_roof) if (k_us or 0) >= (t_us or 0) else (tail_roof, attn_roof)
+        dominant, other = roofline_objects(eng, int(model.hip_precision_used), Bl, T, kern, ms_step, traffic, traffic_src)
         probe = model.hip_precision_probe
         out_json = {
             "metric": f"diffusion-steps/sec (B={B}, T={T}, 22-joint)",
@@ -397,6 +435,9 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": ms_step,
+            # the same K steps as a caller's chain runs them (weights checksummed, plan agreed on, the runtime guard's LayerNorm monitors read
+            # back at the end): `value` times the bare region (those three run in the warm-up call before it / after t1)
+            "ms_per_step_with_checksum_and_guard": ms_step_guarded,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

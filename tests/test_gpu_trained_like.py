@@ -35,6 +35,14 @@ def trained():
     return sd, info
 
 
+@pytest.fixture(scope="module")
+def trained196():
+    from make_trained_like_checkpoint import train_like
+    sd, info = train_like(steps=3000, seed=0, device="cuda", T=196)
+    assert info["loss_last"] < 0.6 * info["loss_first"], info
+    return {k: v for k, v in sd.items() if k.startswith("denoise_fn.")}, info
+
+
 def _build(sd, prec="auto", window=T, **knobs):
     cfg = ModelConfig(max_timesteps=window + 1)
     m = CondGaussianDiffusion(**cfg.ctor_kwargs())
@@ -152,16 +160,13 @@ def test_trained_like_forward_and_chain_against_oracle(trained):
     assert float((got - want).abs().max()) < POSE_TOL, float((got - want).abs().max())
 
 
-def test_trained_like_long_window_against_oracle():
+def test_trained_like_long_window_against_oracle(trained196):
     """The same at BASELINE configs[3]'s window (T = 196: `qkv_i8q_kernel` + `attn_core_i8w_kernel<7>`, V scaled per key, the
     probabilities' scale per query): a checkpoint trained at that length, what `auto` picks for it, one forward and a 50-step
     chain against the oracle.  (Round 4: with two-slice probabilities in the long-window core `auto`'s pick ended this chain
     8.7e-4 from split-bf16 although its probe said 3.5e-4; with three slices 3.6e-4 / 1.7e-4.)"""
-    from make_trained_like_checkpoint import train_like
     W, B, S = 196, 2, 50
-    sd, info = train_like(steps=3000, seed=0, device="cuda", T=W)
-    assert info["loss_last"] < 0.6 * info["loss_first"], info
-    sd = {k: v for k, v in sd.items() if k.startswith("denoise_fn.")}
+    sd, info = trained196
     data = make_motion_windows(B, W, seed=4243)
     mask = head_condition_mask(data.shape)
     g = torch.Generator().manual_seed(78)
@@ -340,8 +345,8 @@ def test_small_jobs_run_split_bf16_unprobed_and_the_verdict_is_cached(tmp_path, 
 def test_whole_chain_at_the_metrics_size_b256(trained):
     """the WHOLE 1000-step chain at B = 256 (BASELINE configs[2]; its first 64 windows = configs[1]) in what `auto`
     picks — for the initialisation and for the trained-like checkpoint — against split-bf16 with the same Philox draws, per window;
-    four windows against the fp32 CPU oracle with the oracle's draws (tools/chain_tail_b256.py; all seeds, both window lengths
-    and every int8 form: profiles/r05_chain_tail_b256.txt).
+    (tools/chain_tail_b256.py; all seeds, both window lengths and every int8 form: profiles/r05_chain_tail_b256.txt; against the fp32
+    oracle: test_whole_chain_against_the_fp32_oracle_on_16_windows below).
     The initialisation's chain does not amplify operand rounding (whole chain / one forward ~1) and runs "9 as is" inside the bar on all 256
     windows; the trained-like checkpoint's does (5-10x), and `auto` answers with split-bf16 (plan.AMPLIFICATION_LIMIT)."""
     from chain_tail_b256 import chain_tail
@@ -359,7 +364,7 @@ def test_whole_chain_at_the_metrics_size_b256(trained):
     sd, info = trained
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        res = chain_tail(sd, T, 256, ("auto", "8pn"), n_oracle=4, log=lambda s: print(s))
+        res = chain_tail(sd, T, 256, ("auto", "8pn"), log=lambda s: print(s))
         sens = sensitivity(sd, T, 256, [1e-6], log=lambda s: print(s))["eps"][1e-6]
     r = res["auto"]
     amp = {k: v for k, v in r["probe"].items() if k.endswith("amplification")}
@@ -373,5 +378,37 @@ def test_whole_chain_at_the_metrics_size_b256(trained):
     n8 = res["8pn"]
     print(f"trained-like, 8 prepared + ffn16 (not what auto runs): worst of 256 windows {n8['vs3']['max']:.2e}, p99 {n8['vs3']['p99']:.2e}")
     assert n8["vs3"]["p99"] <= BAR_VS_SPLIT
+
+
+@pytest.mark.parametrize("window", [120, 196])
+def test_whole_chain_against_the_fp32_oracle_on_16_windows(trained, trained196, window):
+    """what `auto` runs on the trained-like checkpoint — at T = 120 and at T = 196 — over the WHOLE 1000-step chain on 16
+    windows against the fp32 CPU oracle with the oracle's injected draws (~40-60 s of CPU on 16 threads per window length), inside the bar
+    on every window; and the plan's own record stands up to a repeat: a FRESH measurement (no cache) of the same checkpoint picks the same
+    precision and reads the chain's amplification within 2x of what the (possibly cached) plan says — a stale or mis-keyed cache entry
+    would show here."""
+    from chain_tail_b256 import chain_tail
+    from egoego_release_amd import plan
+    sd = (trained if window == 120 else trained196)[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = chain_tail(sd, window, 256, ("auto",), n_oracle=16, log=lambda s: print(s))
+        fresh = _build(sd, window=window, hip_plan_cache=False)
+        fresh.hip_engine(verify=True)
+    r = res["auto"]
     for form in ("auto", "3"):
-        assert max(res[form]["vs_oracle"]) < POSE_TOL, (form, res[form]["vs_oracle"])
+        worst = max(res[form]["vs_oracle"])
+        print(f"T={window} {form}: worst of 16 whole chains against the fp32 oracle {worst:.2e}")
+        assert len(res[form]["vs_oracle"]) == 16 and worst < POSE_TOL, (form, res[form]["vs_oracle"])
+    assert r["vs3"]["max"] < POSE_TOL - max(res["3"]["vs_oracle"])  # all 256 windows: auto against split-bf16 + split-bf16's distance to the oracle
+    fp = fresh.hip_precision_probe
+    assert fresh.hip_precision_used == r["precision"] and fp["source"] == "probe", (fresh.hip_precision_used, r["precision"], fp["source"])
+    amp_plan = {k: v for k, v in r["probe"].items() if k.endswith("amplification")}
+    amp_fresh = {k: v for k, v in fp["errors"].items() if k.endswith("amplification")}
+    print(f"T={window}: plan ({r['source']}) amplification {amp_plan}; fresh {amp_fresh}")
+    assert amp_plan.keys() == amp_fresh.keys() and amp_plan
+    for k in amp_plan:
+        assert 0.5 <= amp_plan[k] / amp_fresh[k] <= 2.0, (k, amp_plan[k], amp_fresh[k])
+    if r["precision"] == _lib.PREC_BF16X3:
+        assert max(amp_plan.values()) > plan.AMPLIFICATION_LIMIT
+    fresh.invalidate_engine()

@@ -5,7 +5,7 @@
 #   2. per-kernel time summaries                         rocprofv3 --kernel-trace --stats  (same commands, fewer steps)
 #   3. PMC counters, three separate passes               rocprofv3 --kernel-trace --pmc ...   (no --sys-trace etc.)
 # (the rocprofv3 runs pass --precision 9 — what "auto" picks for the synthetic weights — so that the probe of "auto" does not mix its small-batch launches into the per-kernel averages)
-R=${EGOEGO_ROUND:-r05}
+R=${EGOEGO_ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
@@ -29,6 +29,10 @@ python3 tools/step_times.py --steps 100 --batches 1,2,8,32 --windows 120,196 --p
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_a -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_a.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_b -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_b.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 9 --no-probe --no-cpu-baseline --no-graph > $O/pmc_c.log 2>&1
+# the same three passes for split-bf16 (precision 3: what "auto" runs on a checkpoint whose chain amplifies operand rounding)
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_a_p3 -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 3 --no-probe --no-cpu-baseline --no-graph > $O/pmc_a_p3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_b_p3 -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 3 --no-probe --no-cpu-baseline --no-graph > $O/pmc_b_p3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_c_p3 -o pmc -- python3 bench.py --steps 3 --warmup 1 --precision 3 --no-probe --no-cpu-baseline --no-graph > $O/pmc_c_p3.log 2>&1
 # calibration of FETCH_SIZE / WRITE_SIZE on known-byte kernels of this library's access shapes (tools/microbench/fetch_calib.hip)
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_f -o pmc -- ./tools/microbench/_bin/fetch_calib > $O/calib_f.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_w -o pmc -- ./tools/microbench/_bin/fetch_calib > $O/calib_w.log 2>&1
