@@ -53,7 +53,7 @@ EG_D i32x4 lds_frag(const char* p) { return *(const i32x4*)p; }
 // ---- the probabilities as THREE int8 slices (round 4) -----------------------------------------------------------------------
 // p = exp2(s - rowmax) lies in (0, 1] with the row's largest entry exactly 1, so one fixed scale serves every row — but two slices
 // (steps of 1 / 32639) leave every small probability an ABSOLUTE error of 1.5e-5, and a trained, peaked attention sums ~120 of them
-// against a small row sum: tools/experiments/int8_site_study.py puts the P image at 4.5e-4 of a trained-like chain's error where
+// against a small row sum: int8_site_study.py (round-4/5 experiment, removed; results: HISTORY.md) puts the P image at 4.5e-4 of a trained-like chain's error where
 // everything else together (prepared packing) makes 2.6e-4, and Q, K, V images add nothing.  So P gets a third slice:
 //     q = rint(p * 8355711) = 65536 a1 + 256 a2 + a3   (a1 in 0..127, a2, a3 signed bytes; 8355711 = 127 * 65536 + 127 * 256 + 127:
 //     the top slice keeps the 7 bits the two-slice form had, so the dropped a2 v2 term is no larger than its b2 v2 was — with a1

@@ -46,7 +46,7 @@ AMPLIFICATION_LIMIT = 3.0  # stage 2: the whole chain's worst window over ONE fo
                          # chain ends where its last forward ends).  Trained-like checkpoints: 5-10 — their chains ACCUMULATE operand rounding,
                          # heavy-tailed over windows: in 2 of 6 (checkpoint, window length) pairs a batch or probe of 128-256 windows held a window
                          # whose last 50 steps multiply any difference along one direction by ~11 and end 1e-2 away in EVERY int8 form
-                         # (tools/experiments/outlier_window.py), while the other windows sat at 5-8e-4 — no sample of windows bounds that tail.  So a
+                         # (outlier_window.py (round-4/5 experiment, removed; results: HISTORY.md)), while the other windows sat at 5-8e-4 — no sample of windows bounds that tail.  So a
                          # 16-bit fixed-point form is accepted only for a checkpoint whose chain does not amplify it; otherwise "auto" is split-bf16
 SMALL_JOB_WINDOW_STEPS = 16 * 1000       # "auto", chain-level calls: below this many window-steps the job is shorter than the probe
 PROBE_AFTER_STEPS = 8 * 1000             # ... until one module has run this many STEPS unprobed: small jobs are launch-bound (0.43 ms per step in split-bf16

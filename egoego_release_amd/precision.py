@@ -4,7 +4,7 @@ The int8 precisions are 16-bit FIXED point with one scale per row (activations) 
 FLOATING point per element.  On the reference's initialisation both are far inside the 1e-3 bar; on weights that have been trained
 the fixed-point grid is about three bits coarser where it matters (measured on the trained-like checkpoint of
 tools/make_trained_like_checkpoint.py, round 4: precision 9 ends a chain 1.17e-3 from the fp32 oracle, precision 8 8.7e-4,
-precision 3 6e-5; tools/experiments/int8_site_study.py attributes 7.4e-4 of it to the WEIGHT grid alone — nearest rounding of the
+precision 3 6e-5; int8_site_study.py (round-4/5 experiment, removed; results: HISTORY.md) attributes 7.4e-4 of it to the WEIGHT grid alone — nearest rounding of the
 Q/K/V projections of a sharp, trained attention — and most of the rest to LayerNorm rows that carry one near-constant massive
 feature).  Two pack-time transformations, both invisible to the kernels and free at run time, buy most of it back:
 

@@ -39,7 +39,7 @@ def _ref_noise(shape, S, seed=123):
 def test_stagewise_against_oracle(prec):
     B, T, H = 2, 120, 4
     # precision 9: the stops run the PRODUCT kernels and tap their int8 rows: 16-bit FIXED point per row, so the error of a tap scales
-    # with its row's maximum (values up to ~5 -> steps of 1.5e-4).  Measured (tools/experiments/gain_cases.py, round 5): <= 2.2e-4 of the
+    # with its row's maximum (values up to ~5 -> steps of 1.5e-4).  Measured (gain_cases.py (round-4/5 experiment, removed; results: HISTORY.md), round 5): <= 2.2e-4 of the
     # row maximum at every stop, 6.4e-4 absolute at the last layer's output; split-bf16: <= 5.4e-5 absolute.
     cfg, sd, m = _model(T, precision=prec)
     eng = m.hip_engine()
@@ -551,7 +551,7 @@ def test_outlier_heavy_layernorm_gains_step_the_default_precision_down():
     int8 slices against split-bf16 on a probe batch): the reference's initialisation runs precision 9 with no warning; the SAME
     six features amplified 25x in every LayerNorm (the worst case found, tools/gain_sweep.py) — and already 3x — step down to
     split-bf16, with a warning, and the stepped-down result is inside the bar; 2x runs precision 8 as is, silently, inside the bar
-    (every outcome below is what tools/experiments/gain_cases.py measured in round 5, pinned); an explicit int8 precision is kept and
+    (every outcome below is what gain_cases.py (round-4/5 experiment, removed; results: HISTORY.md) measured in round 5, pinned); an explicit int8 precision is kept and
     warned about."""
     import warnings
     cfg = ModelConfig(max_timesteps=121)
