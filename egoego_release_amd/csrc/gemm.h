@@ -35,6 +35,18 @@
 #define EG_DBG(...)
 #endif
 
+// EGOEGO_GEMM_BUFFER_DMA (round 6, A/B knob of variant builds): the ring's LDS-DMA requests as `buffer_load_dwordx4 ... lds` — one buffer
+// resource per operand in SGPRs, a wave-uniform byte offset in an SGPR, the lane's 16 bytes as a constant VGPR offset — instead of
+// `global_load_lds_dwordx4` on a per-lane 64-bit pointer (two VALU adds per request and 2 NCH address VGPRs).  Same bytes to the same place.
+#ifndef EGOEGO_GEMM_BUFFER_DMA
+#define EGOEGO_GEMM_BUFFER_DMA 0
+#endif
+EG_D __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
+// one 1-KiB piece: 16 bytes per lane from resource `r` at byte offset `soff` (wave-uniform) + 16 * lane into LDS at `dst` + 16 * lane
+EG_D void gemm_dma_piece(__amdgpu_buffer_rsrc_t r, char* dst, unsigned soff, int lane) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, soff, 0, 0);
+}
+
 struct GemmOperands {
     const __bf16* w;  // weights, fragment-tiled [N][K]; lo plane at w + w_plane
     size_t w_plane;
@@ -158,6 +170,8 @@ struct GemmBody {
         const int ns = (g.kcount ? g.kcount : g.K16) / KS;
         const u32x4* gp[NCH];
         int dsto[NCH];
+        unsigned boff[NCH];  // (buffer form) byte offset of chunk j's block inside its operand's resource
+        bool isw[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int blk = min(j * NW + wave, C::NBLK - 1);
@@ -167,21 +181,32 @@ struct GemmBody {
             if (t2 < WT * NP) {
                 const int p = t2 / WT, i = t2 % WT;
                 base = (const u32x4*)(g.w + (size_t)p * g.w_plane) + ((size_t)(fblk * WT + i) * g.K16 + ks) * 64;
+                boff[j] = (unsigned)(p * g.w_plane * 2) + (unsigned)(((fblk * WT + i) * g.K16 + ks) << 10);
+                isw[j] = true;
             } else {
                 const int t3 = t2 - WT * NP;
                 const int p = t3 / AT, i = t3 % AT;
                 base = (const u32x4*)(g.a + (size_t)p * g.a_plane) + ((size_t)(tblk * AT + i) * g.K16 + ks) * 64;
+                boff[j] = (unsigned)(p * g.a_plane * 2) + (unsigned)((i * g.K16 + ks) << 10);
+                isw[j] = false;
             }
             gp[j] = base + lane;
         }
+        const __amdgpu_buffer_rsrc_t wr = gemm_rsrc(g.w), ar = gemm_rsrc(g.a + ((size_t)tblk * AT * g.K16 << 9));
         // (stage 0's requests before stage 1's: the main loop's first counted wait leaves exactly the newest stage in flight)
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (d < ns) {
 #pragma unroll
-                for (int j = 0; j < NCH; ++j)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (size_t)d * KS * 64),
-                                                     (__attribute__((address_space(3))) void*)(smem + (size_t)d * C::STAGE_BYTES + dsto[j]), 16, 0, 0);
+                for (int j = 0; j < NCH; ++j) {
+                    if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0) {
+                        char* dst = smem + (size_t)d * C::STAGE_BYTES + dsto[j];
+                        if (isw[j]) gemm_dma_piece(wr, dst, boff[j] + (unsigned)(d * KS * 1024), lane);
+                        else gemm_dma_piece(ar, dst, boff[j] + (unsigned)(d * KS * 1024), lane);
+                    } else
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (size_t)d * KS * 64),
+                                                         (__attribute__((address_space(3))) void*)(smem + (size_t)d * C::STAGE_BYTES + dsto[j]), 16, 0, 0);
+                }
             }
     }
     template <class AccT, bool ZERO = true, class Pre = NoPre, bool PREFETCHED = false>
@@ -201,6 +226,8 @@ struct GemmBody {
         // Per-thread source pointers of this stage's chunks (wave-uniform base + lane).
         const u32x4* gp[NCH];
         int dsto[NCH];  // byte offset of chunk j's block inside a stage
+        unsigned boff[NCH];  // (buffer form) byte offset of chunk j's block inside its operand's resource: wave-uniform, lives in an SGPR
+        bool isw[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int blk = min(j * NW + wave, C::NBLK - 1);
@@ -210,13 +237,19 @@ struct GemmBody {
             if (t2 < WT * NP) {
                 const int p = t2 / WT, i = t2 % WT;
                 base = (const u32x4*)(g.w + (size_t)p * g.w_plane) + ((size_t)(fblk * WT + i) * g.K16 + ks) * 64;
+                boff[j] = (unsigned)(p * g.w_plane * 2) + (unsigned)(((fblk * WT + i) * g.K16 + ks) << 10);
+                isw[j] = true;
             } else {
                 const int t3 = t2 - WT * NP;
                 const int p = t3 / AT, i = t3 % AT;
                 base = (const u32x4*)(g.a + (size_t)p * g.a_plane) + ((size_t)(tblk * AT + i) * g.K16 + ks) * 64;
+                boff[j] = (unsigned)(p * g.a_plane * 2) + (unsigned)((i * g.K16 + ks) << 10);
+                isw[j] = false;
             }
             gp[j] = base + lane;
         }
+        // (buffer form) the weights from their base, the activations from this token block's first row tile: offsets stay far below 2^31
+        const __amdgpu_buffer_rsrc_t wr = gemm_rsrc(g.w), ar = gemm_rsrc(g.a + ((size_t)tblk * AT * g.K16 << 9));
 
         if (ZERO) {
 #pragma unroll
@@ -263,9 +296,13 @@ struct GemmBody {
         };
         auto issue_one = [&](int stage, int slot, int j) {
             char* dst = smem + (size_t)slot * C::STAGE_BYTES;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(gp[j] + (size_t)stage * KS * 64),
-                (__attribute__((address_space(3))) void*)(dst + dsto[j]), 16, 0, 0);
+            if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0) {
+                if (isw[j]) gemm_dma_piece(wr, dst + dsto[j], boff[j] + (unsigned)(stage * KS * 1024), lane);
+                else gemm_dma_piece(ar, dst + dsto[j], boff[j] + (unsigned)(stage * KS * 1024), lane);
+            } else
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(gp[j] + (size_t)stage * KS * 64),
+                    (__attribute__((address_space(3))) void*)(dst + dsto[j]), 16, 0, 0);
         };
         // MFMAs of one half (FH x TT accumulator triples, part-major).  DMA instruction q of (stage, slot) is issued
         // after MFMA q - q0, so the DMA issue cost is paid in the shadow of the matrix pipe.
