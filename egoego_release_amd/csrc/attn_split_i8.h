@@ -453,12 +453,16 @@ __global__ __launch_bounds__(512, 2) void attn_core_s_kernel(AttnLayerArgs a, At
     const int lane = threadIdx.x & 63, hf = lane >> 5, col = lane & 31;
     const int8_t* const img = o.img + (size_t)bh * 3 * 65536;
     // an image = 64 one-KiB pieces, 8 per wave (both slices)
+    const __amdgpu_buffer_rsrc_t ir = gemm_rsrc(img);  // (buffer form, common.h: the three images of this (window, head), 192 KiB)
     auto dma_image = [&](const int8_t* src, char* dst) {
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
             const int pc = n * 8 + wave;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((size_t)pc << 10) + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
+            if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0)
+                gemm_dma_piece(ir, dst + (pc << 10), (unsigned)(src - img) + (unsigned)(pc << 10), lane);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((size_t)pc << 10) + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + (pc << 10)), 16, 0, 0);
         }
     };
     dma_image(img + 65536, kv);    // K

@@ -183,6 +183,21 @@ EG_D void wait_counts() {
 }
 EG_D void wait_lds() { wait_counts<63, 0>(); }
 
+// LDS-DMA requests as `buffer_load_dwordx4 ... lds` (round 6): one buffer resource per operand in SGPRs, a wave-uniform byte offset in an
+// SGPR, the lane's 16 bytes as a constant VGPR offset — instead of `global_load_lds_dwordx4` on a per-lane 64-bit pointer (two VALU adds
+// per request and an address VGPR pair per chunk).  Same bytes to the same place: bit-equal results (9 tensors over the three precisions,
+// T = 30 / 120 / 196), and 2-3 % less time per step in every configuration measured (profiles/r06_buffer_dma_ab.txt: B=256 x T=120 1.414 ->
+// 1.384 ms in precision 9, 2.408 -> 2.336 in split-bf16; B=32 0.306 -> 0.299 / 0.520 -> 0.505; T=196 3.055 -> 3.004 / 4.681 -> 4.525).
+// EGOEGO_GEMM_BUFFER_DMA=0: the global form (variant builds, A/B).  Offsets are 32-bit: every resource is based so that they stay far below 2^31.
+#ifndef EGOEGO_GEMM_BUFFER_DMA
+#define EGOEGO_GEMM_BUFFER_DMA 1
+#endif
+EG_D __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
+// one 1-KiB piece: 16 bytes per lane from resource `r` at byte offset `soff` (wave-uniform) + 16 * lane into LDS at `dst` + 16 * lane
+EG_D void gemm_dma_piece(__amdgpu_buffer_rsrc_t r, char* dst, unsigned soff, int lane) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, soff, 0, 0);
+}
+
 EG_D int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // Row of accumulator register r of v_mfma_f32_32x32x16_bf16 for a lane in half hf (= lane >> 5):

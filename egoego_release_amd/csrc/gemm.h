@@ -35,18 +35,6 @@
 #define EG_DBG(...)
 #endif
 
-// EGOEGO_GEMM_BUFFER_DMA (round 6, A/B knob of variant builds): the ring's LDS-DMA requests as `buffer_load_dwordx4 ... lds` — one buffer
-// resource per operand in SGPRs, a wave-uniform byte offset in an SGPR, the lane's 16 bytes as a constant VGPR offset — instead of
-// `global_load_lds_dwordx4` on a per-lane 64-bit pointer (two VALU adds per request and 2 NCH address VGPRs).  Same bytes to the same place.
-#ifndef EGOEGO_GEMM_BUFFER_DMA
-#define EGOEGO_GEMM_BUFFER_DMA 0
-#endif
-EG_D __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
-// one 1-KiB piece: 16 bytes per lane from resource `r` at byte offset `soff` (wave-uniform) + 16 * lane into LDS at `dst` + 16 * lane
-EG_D void gemm_dma_piece(__amdgpu_buffer_rsrc_t r, char* dst, unsigned soff, int lane) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, soff, 0, 0);
-}
-
 struct GemmOperands {
     const __bf16* w;  // weights, fragment-tiled [N][K]; lo plane at w + w_plane
     size_t w_plane;
