@@ -94,14 +94,15 @@ def hip_steps_fn(model, t_start, n_steps, seed=0, group=None, verify=True, guard
         dev = model.betas.device
         x = noise["x_T"].to(dev, torch.float32).contiguous().clone()
         job = (int(global_windows if global_windows is not None else x.shape[0]), int(x.shape[1]), int(n_steps))
-        eng = model.hip_engine(verify=verify, job=job, group=grp if verify else None)
+        x_cond = x
         if x.shape[0]:
             xs, cm = xs.to(dev), cm.to(dev)
             x_cond = (xs * (1.0 - cm) + cm * noise["cond"].to(dev)).float().contiguous()
+        # (this shard's conditions shape stage 2 of the plan's measurement: group rank 0's, which holds the batch's first windows)
+        eng = model.hip_engine(verify=verify, job=job, group=grp if verify else None, conditions=x_cond if x.shape[0] else None)
+        if x.shape[0]:
             eng.sample_loop_(x, x_cond, t_start, n_steps, noise_mode=_lib.NOISE_PHILOX, seed=seed, window_offset=window_offset)
             model._note_job((x.shape[0], x.shape[1], n_steps))
-        else:
-            x_cond = x
         fn.last = (eng, x, x_cond)
         if guard:
             model._outlier_guard(eng, x, x_cond, group=grp)

@@ -256,6 +256,7 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
     device = model.betas.device
     if b == 0:
         empty = torch.zeros((0, seq_len, 198), device=device)
+        eng = model.hip_engine(verify=True, job=job, group=group)  # (mirrors the other ranks' second call, the one that hands the first window's conditions over)
         for _ in spans:
             model._outlier_guard(eng, empty, empty, group=group)
             eng = model.hip_engine()  # (a collective step-down re-packs here too: this rank must leave the int8 precision with the others)
@@ -292,6 +293,8 @@ def p_sample_loop_sliding_window_w_canonical(model, ds, shape, global_head_jpos,
         cn = noise["cond"][w_idx].to(device) if noise is not None else torch.randn_like(x_start)
         x_cond = (x_start * (1.0 - cm) + cm * cn).float().contiguous()
         pfx = prefix if t_idx > 0 else None
+        if t_idx == 0:  # (the first window's conditions shape stage 2 of the plan's measurement; collective like the call above)
+            eng = model.hip_engine(verify=True, job=job, group=group, conditions=x_cond)
         if noise is not None and "steps" in noise:
             eng.sample_loop_(curr_x, x_cond, S - 1, S, noise=noise["steps"][w_idx].to(device).float().contiguous(), prefix=pfx)
         elif model.sampling_rng == "philox" or noise is not None:

@@ -160,6 +160,7 @@ class _EngineSlot:
         self.demoted = False   # the runtime guard measured the int8 precision outside the limit on live inputs: "auto" now means 3
         self.force_repack = False  # ... and asked for the re-pack that applies it (a re-pack for any other reason clears `demoted`)
         self.unprobed_work = 0     # steps sampled on a "small job" context (split-bf16, no probe): plan.is_small_job
+        self.caller_checked = False  # the plan was measured once more on a caller's conditions (at most once per packed weights)
 
     def __deepcopy__(self, memo):
         return _EngineSlot()
@@ -281,6 +282,7 @@ class CondGaussianDiffusion(nn.Module):
         self._slot.noise_buf = None
         self._slot.envelope, self._slot.demoted, self._slot.force_repack = None, False, False
         self._slot.unprobed_work = 0
+        self._slot.caller_checked = False
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -293,7 +295,7 @@ class CondGaussianDiffusion(nn.Module):
             self.invalidate_engine()
         return out
 
-    def hip_engine(self, verify=False, masked=False, job=None, group=None):
+    def hip_engine(self, verify=False, masked=False, job=None, group=None, conditions=None):
         """The HIP context for the module's current device/weights (packed lazily, re-packed when parameters change
         or the module moves).  verify=True (every chain-level entry point: sample, p_sample_loop, ddim_sample, the
         sliding-window harness) additionally compares a device-side checksum of the weights with the one taken when
@@ -302,7 +304,9 @@ class CondGaussianDiffusion(nn.Module):
         job=(windows, frames, steps): the chain-level call this context is for — under hip_precision="auto" a job shorter than the
         precision probe runs split-bf16 unprobed (plan.py).  group: a torch.distributed process group whose ranks must all sample
         from ONE plan (dist.py passes it): every rank reports whether its packed copy is stale, and if any is, group rank 0
-        resolves the plan and broadcasts it (prepared tensors included) — call it on every rank of the group."""
+        resolves the plan and broadcasts it (prepared tensors included) — call it on every rank of the group.
+        conditions: the x_cond rows [n, T, D] of the chain-level call (T = seq_len): stage 2 of the measurement runs on them, and an int8 form
+        accepted earlier on the probe's self-generated conditions is measured once more on these (plan.wants_caller_conditions)."""
         dev = self.betas.device
         if dev.type != "cuda":
             raise _lib.EgoEgoHipError(
@@ -311,12 +315,17 @@ class CondGaussianDiffusion(nn.Module):
         slot = self._slot
         key = self._engine_key()
         fp = self._weights_fingerprint() if (verify or group is not None) else None
-        stale = (slot.engine is None or slot.key != key or (fp is not None and slot.fingerprint != fp) or slot.force_repack
+        if conditions is not None and not (conditions.dim() == 3 and conditions.shape[0] >= 1 and int(conditions.shape[1]) == int(self.seq_len)):
+            conditions = None  # (a shorter trailing window of the harness, an empty shard: the probe keeps its own)
+        remeasure = (slot.engine is not None and slot.key == key and not slot.force_repack and not slot.caller_checked and job is not None
+                     and not plan_mod.is_small_job(self, job) and plan_mod.wants_caller_conditions(self, slot.plan, conditions))
+        stale = (slot.engine is None or slot.key != key or (fp is not None and slot.fingerprint != fp) or slot.force_repack or remeasure
                  or (slot.plan is not None and slot.plan["source"] == "small job" and job is not None and not plan_mod.is_small_job(self, job)))
         synced = group is not None and _world(group) > 1
         if synced:
             # one all_reduce, always: is any rank's copy stale, and do all ranks hold the same weights?
-            got = plan_mod.group_max([1.0 if stale else 0.0, fp[0], -fp[0], fp[1], -fp[1]], group)
+            got = plan_mod.group_max([1.0 if stale else 0.0, fp[0], -fp[0], fp[1], -fp[1], 1.0 if remeasure else 0.0], group)
+            remeasure = got[5] > 0
             if got[1] != -got[2] or got[3] != -got[4]:
                 raise _lib.EgoEgoHipError("the ranks of the process group hold different weights (checksums differ): window-sharded "
                                           "sampling needs the same checkpoint on every rank")
@@ -326,6 +335,7 @@ class CondGaussianDiffusion(nn.Module):
                 if e is not None:
                     e.close()
             slot.engine = slot.engine_masked = None
+            slot.caller_checked = bool(remeasure)
             if not slot.force_repack:
                 slot.demoted = False  # new weights / device / settings: measured afresh
             slot.force_repack = False
@@ -336,7 +346,7 @@ class CondGaussianDiffusion(nn.Module):
                 plan, failure = None, None
                 if tdist.get_rank(group) == 0:
                     try:
-                        plan = plan_mod.resolve(self, job, fp)
+                        plan = plan_mod.resolve(self, job, fp, conditions, remeasure)
                     except Exception as e:  # (out of memory in the probe, ...: the peers wait in the broadcast and must hear about it)
                         failure, plan = e, {"error": repr(e)}
                 plan = plan_mod.group_broadcast(plan, group)
@@ -346,7 +356,7 @@ class CondGaussianDiffusion(nn.Module):
                     raise _lib.EgoEgoHipError(f"group rank 0 failed while resolving the precision plan: {plan['error']}")
                 plan = dict(plan, source=plan["source"] if tdist.get_rank(group) == 0 else f"group rank 0 ({plan['source']})")
             else:
-                plan = plan_mod.resolve(self, job, fp)
+                plan = plan_mod.resolve(self, job, fp, conditions, remeasure)
             slot.plan = plan
             plan_mod.adopt(self, plan)
             slot.engine = HipEngine(_engine_cfg(self), plan["sd"] if plan["sd"] is not None else self.state_dict(), dev, plan["precision"],
@@ -511,8 +521,9 @@ class CondGaussianDiffusion(nn.Module):
         (sampling_rng='philox').
         """
         job = (int(shape[0]), int(shape[1]), int(self.num_timesteps))
-        eng = self.hip_engine(verify=True, masked=padding_mask is not None, job=job)
         device = self.betas.device
+        if device.type != "cuda":
+            self.hip_engine()  # (raises: no CPU path)
         S = self.num_timesteps
         if noise is not None:
             x = self._f32c(noise["x_T"].to(device)).clone()
@@ -521,6 +532,8 @@ class CondGaussianDiffusion(nn.Module):
             x = torch.randn(shape, device=device)
             cn = torch.randn_like(x_start).to(x_start.device)
         x_cond = self._f32c(x_start * (1.0 - cond_mask) + cond_mask * cn)
+        # (after the draws, which keeps the reference's RNG order whatever the measurement does; the caller's conditions shape its stage 2)
+        eng = self.hip_engine(verify=True, masked=padding_mask is not None, job=job, conditions=x_cond)
         pfx = None if prefix is None else self._f32c(prefix)
         # padding_mask reaches every step's denoiser pass like in the reference (M:259, 268), inside the one HIP loop
         if noise is not None:
@@ -574,13 +587,15 @@ class CondGaussianDiffusion(nn.Module):
         noise keyed by `philox_seed`; eta=1 with n_steps=num_timesteps is the ancestral chain).  Not part of the
         reference (it only has the full ancestral chain); provided for BASELINE config 4."""
         job = (int(x_start.shape[0]), int(x_start.shape[1]), int(n_steps))
-        eng = self.hip_engine(verify=True, job=job)
         device = self.betas.device
+        if device.type != "cuda":
+            self.hip_engine()  # (raises: no CPU path)
         if noise is not None:
             x, cn = self._f32c(noise["x_T"].to(device)).clone(), noise["cond"].to(device)
         else:
             x, cn = torch.randn(x_start.shape, device=device), torch.randn_like(x_start)
         x_cond = self._f32c(x_start * (1.0 - cond_mask) + cond_mask * cn)
+        eng = self.hip_engine(verify=True, job=job, conditions=x_cond)
         ts = sorted({int(round(v)) for v in np.linspace(0, self.num_timesteps - 1, n_steps)}, reverse=True)
         eng.ddim_loop_(x, x_cond, ts, eta=eta, seed=self.philox_seed)
         self._note_job(job)

@@ -48,6 +48,15 @@ AMPLIFICATION_LIMIT = 3.0  # stage 2: the whole chain's worst window over ONE fo
                          # whose last 50 steps multiply any difference along one direction by ~11 and end 1e-2 away in EVERY int8 form
                          # (outlier_window.py (round-4/5 experiment, removed; results: HISTORY.md)), while the other windows sat at 5-8e-4 — no sample of windows bounds that tail.  So a
                          # 16-bit fixed-point form is accepted only for a checkpoint whose chain does not amplify it; otherwise "auto" is split-bf16
+GAIN_LIMIT = 0.5         # stage 2 (round 6): the chain's own response to a deliberate perturbation, in split-bf16 alone (precision.PrecisionProbe.chain_gain:
+                         # 1e-4 x N(0, 1) added to x with 40 % of the chain to go; per window |difference of the final poses|max / 1e-4).  The worst window
+                         # of the chain batch must contract it to less than this ...
+GAIN_TAIL_LIMIT = 2.5    # ... AND to less than this multiple of the median window: the response must not be heavy-tailed over windows.  Measured along
+                         # training (profiles/r06_contraction_vs_training.txt, r06_amplification_vs_training.txt; 256 windows): the initialisation max 0.20 /
+                         # median 0.14 (x1.4), 10 and 30 Adam steps 0.11 / 0.08 and 0.09 / 0.07 (x1.3) — every int8 form inside the bar on all 256
+                         # windows there; 50 steps 1.55 / 0.08 (x19), 100 steps 1.14 / 0.09 (x13), 300 steps 1.8 / 0.23, 1000-3000 steps 2.2-2.3 / 0.6-0.7 —
+                         # and there "9 as is" held windows 2.3e-3 (50 steps: ONE of 256, where the chain / forward ratio above read 1.1) to 7e-3 away.  An
+                         # error-based figure sees only the windows it samples; the tail of this one moves from x1.4 to x3-19 before any of them fails
 SMALL_JOB_WINDOW_STEPS = 16 * 1000       # "auto", chain-level calls: below this many window-steps the job is shorter than the probe
 PROBE_AFTER_STEPS = 8 * 1000             # ... until one module has run this many STEPS unprobed: small jobs are launch-bound (0.43 ms per step in split-bf16
                                          # against 0.23 in precision 9 whatever the batch, round 5), so each unprobed step loses ~0.2 ms and 8 chains of 1000 steps
@@ -92,12 +101,13 @@ def masked_state(plan, sd):
 
 
 # ------------------------------------------------------------------------------------------------------------------ the ladder
-def run_ladder(model):
+def run_ladder(model, conditions=None):
+    """conditions: [n, T, D] x_cond rows of the chain-level call the context is packed for (stage 2 then runs on them) or None."""
     want = model.hip_precision
     explicit = want != "auto" or model.hip_plan_override is not None
     full_chain = model.hip_probe_full_chain and (want == "auto" or model.hip_plan_override is not None)
-    probe = PrecisionProbe(model, tail=PROBE_TAIL, chain_windows=CHAIN_WINDOWS)
-    errors, calib, pick, best, rounded, amplifies = {}, None, None, None, {}, None
+    probe = PrecisionProbe(model, tail=PROBE_TAIL, chain_windows=CHAIN_WINDOWS, conditions=conditions)
+    errors, calib, pick, best, rounded, amplifies, unstable = {}, None, None, None, {}, None, None
     try:
         sd = probe.sd
         for prec, prepared, flags in ladder(model):
@@ -122,7 +132,13 @@ def run_ladder(model):
                     errors[f"{prec} {fname}, full chain"] = cerr
                     errors[f"{prec} {fname}, amplification"] = cerr / fwd
                     cand["chain_per_window"] = per_window
+                    gain = probe.chain_gain()
+                    if gain is not None:
+                        errors["chain gain, max"], errors["chain gain, median"] = gain
                     if not explicit:
+                        if gain is not None and (gain[0] > GAIN_LIMIT or gain[0] > GAIN_TAIL_LIMIT * gain[1]):
+                            unstable = gain  # a property of the checkpoint's chain (measured in split-bf16 alone): no int8 form is tried further
+                            break
                         if cerr / fwd > AMPLIFICATION_LIMIT:
                             amplifies = (prec, fname, cerr / fwd)  # a property of the checkpoint's chain, not of this packing: no int8 form is tried further
                             break
@@ -134,7 +150,13 @@ def run_ladder(model):
         probe.close()
     shown = ", ".join(f"precision {k}: {e:.1e}" for k, e in errors.items())
     warn = None
-    if pick is None and not explicit and amplifies is not None:
+    if pick is None and not explicit and unstable is not None:
+        plan = plain_plan(_lib.PREC_BF16X3, "probe")
+        warn = (f"hip_precision='auto': this checkpoint's sampling chain does not contract a perturbation evenly over windows (1e-4 x N(0,1) added with "
+                f"{probe.t_gain} steps to go moves the final pose by up to {unstable[0]:.2f}x its size, median window {unstable[1]:.2f}x; limits {GAIN_LIMIT} and "
+                f"{GAIN_TAIL_LIMIT}x the median, on {probe.conditions} conditions) — such a chain holds windows that multiply 16-bit fixed-point rounding beyond "
+                f"the bar (DESIGN.md 3c), so split-bf16 (3) runs, ~85 % more time per step; measured: {shown}.  An explicit hip_precision = 8 / 9 overrides this")
+    elif pick is None and not explicit and amplifies is not None:
         plan = plain_plan(_lib.PREC_BF16X3, "probe")
         warn = (f"hip_precision='auto': this checkpoint's sampling chain amplifies operand rounding {amplifies[2]:.1f}x (precision {amplifies[0]} {amplifies[1]}: the worst of "
                 f"{CHAIN_WINDOWS} whole chains over one forward's error; limit {AMPLIFICATION_LIMIT:.0f}x) — on such a chain single windows of a large batch end "
@@ -153,6 +175,7 @@ def run_ladder(model):
         plan = dict(pick, source="probe")
     chosen = pick if pick is not None else (best[1] if explicit else None)
     plan["probe"] = {"errors": errors, "limit": PROBE_LIMIT, "chain_limit": CHAIN_LIMIT, "chain_windows": CHAIN_WINDOWS, "amplification_limit": AMPLIFICATION_LIMIT,
+                     "gain_limits": (GAIN_LIMIT, GAIN_TAIL_LIMIT), "conditions": probe.conditions,
                      "row_max": chosen["envelope"] if chosen else None, "prepared": bool(chosen and chosen["prepared"]),
                      "form": chosen["form"] if chosen else None,
                      "chain_per_window": chosen.get("chain_per_window") if chosen else None}
@@ -189,7 +212,7 @@ def cache_key(model, fingerprint):
     what = [_lib.ABI_VERSION, _lib_hash(), [repr(v) for v in fingerprint], sorted(_engine_cfg(model).items()), str(model.hip_precision),
             model.hip_int8_prep, bool(model.hip_fc24), bool(model.hip_ffn16), bool(model.hip_probe_full_chain),
             list(model.hip_plan_override) if model.hip_plan_override is not None else None,
-            PROBE_LIMIT, PROBE_TAIL, CHAIN_WINDOWS, CHAIN_LIMIT, AMPLIFICATION_LIMIT,
+            PROBE_LIMIT, PROBE_TAIL, CHAIN_WINDOWS, CHAIN_LIMIT, AMPLIFICATION_LIMIT, GAIN_LIMIT, GAIN_TAIL_LIMIT,
             torch.cuda.get_device_name(model.betas.device) if model.betas.device.type == "cuda" else str(model.betas.device)]
     return hashlib.sha256(json.dumps(what, sort_keys=True, default=str).encode()).hexdigest()[:32]
 
@@ -261,9 +284,25 @@ def is_small_job(model, job):
     return b * steps < SMALL_JOB_WINDOW_STEPS and model._slot.unprobed_work < PROBE_AFTER_STEPS
 
 
-def resolve(model, job=None, fingerprint=None):
+def measured_on_caller(plan):
+    return bool(plan and plan.get("probe") and str(plan["probe"].get("conditions", "")).startswith("caller"))
+
+
+def wants_caller_conditions(model, plan, conditions):
+    """An int8 form that `auto` accepted on the probe's SELF-GENERATED conditions is measured once more on the caller's own, the first time a
+    chain-level call hands some over (model.hip_engine(conditions=...)): what a chain does to rounding depends on what it is conditioned on."""
+    if conditions is None or plan is None or model.hip_precision != "auto" or model.hip_plan_override is not None:
+        return False
+    if plan["precision"] not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC) or plan["source"] not in ("probe", "cache") and not str(plan["source"]).startswith("group rank 0"):
+        return False
+    ok_shape = conditions.dim() == 3 and conditions.shape[0] >= 1 and int(conditions.shape[1]) == int(model.seq_len)
+    return ok_shape and model.hip_probe_full_chain and not measured_on_caller(plan)
+
+
+def resolve(model, job=None, fingerprint=None, conditions=None, remeasure=False):
     """-> plan dict {"precision", "sd" (None = the module's own state dict), "row_shift", "prepared", "flags", "form", "source",
-    "probe", "envelope", "warn"}.  `job` = (windows, frames, steps) of the chain-level call that needs the context, or None."""
+    "probe", "envelope", "warn"}.  `job` = (windows, frames, steps) of the chain-level call that needs the context, or None.
+    conditions: that call's x_cond rows (stage 2 runs on them); remeasure: skip the cache READ (the verdict is written)."""
     want = model.hip_precision
     if model.hip_plan_override is None and want != "auto" and want not in (_lib.PREC_I8X3, _lib.PREC_I8X3_FC):
         return plain_plan(want, "explicit")
@@ -274,14 +313,14 @@ def resolve(model, job=None, fingerprint=None):
     key = None
     if model.hip_plan_cache and cache_dir() is not None:
         key = cache_key(model, fingerprint if fingerprint is not None else model._weights_fingerprint())
-        hit = cache_load(key)
+        hit = None if remeasure else cache_load(key)
         if hit is not None:
             return dict(hit, source="cache", cache_key=key)
     if is_small_job(model, job):
         return plain_plan(_lib.PREC_BF16X3, "small job",
                           {"skipped": f"a job of {job[0]} windows x {job[2]} steps is shorter than the precision probe: split-bf16 (no verdict "
                                       f"cached for these weights; jobs of >= {SMALL_JOB_WINDOW_STEPS} window-steps, or model.hip_engine(), measure)"})
-    plan = run_ladder(model)
+    plan = run_ladder(model, conditions)
     if key is not None:
         cache_store(key, plan)
         plan["cache_key"] = key

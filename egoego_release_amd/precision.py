@@ -46,7 +46,10 @@ class PrecisionProbe:
     B = 4
     SEED = 20260401
 
-    def __init__(self, model, probe=None, tail=30, chain_windows=None):
+    GAIN_EPS = 1e-4        # size of the deliberate perturbation of `chain_gain` (per element, N(0, 1) x this)
+    GAIN_AT = 0.4          # ... added to x when this fraction of the chain is still to run (the tails showed most there: r06_contraction_vs_training.txt)
+
+    def __init__(self, model, probe=None, tail=30, chain_windows=None, conditions=None):
         self.model = model
         self.dev = model.betas.device
         self.cfg = _engine_cfg(model)
@@ -75,7 +78,20 @@ class PrecisionProbe:
         # stage 2 (`chain_error`): whole chains from noise on MORE windows than stage 1 — what a chain loses is heavy-tailed over
         # windows (round 4: 2.2x between the best and the worst of 8), and a 32-window chain costs a third more than a 4-window one
         self.xT_chain, self.xc_chain = self.xT, self.xc
-        if probe is None and chain_windows is not None and chain_windows > B:
+        self.conditions = "probe batch"
+        if probe is None and chain_windows is not None and conditions is not None and conditions.shape[0] >= 1 and tuple(conditions.shape[1:]) == (T, D):
+            # stage 2 on the CALLER's own conditions (round 6): the x_cond rows of the chain-level call this context is packed for, cycled up to
+            # `chain_windows` windows.  What a chain does to a perturbation depends on what it is conditioned on: a barely trained checkpoint's
+            # self-generated conditions (below) excite none of the window-specific instabilities that real head trajectories do — the probe
+            # read 4.8e-4 where the caller's 256 windows held 4.5e-3 (profiles/r06_amplification_vs_training.txt)
+            gc = torch.Generator().manual_seed(self.SEED + 2)
+            n = int(conditions.shape[0])
+            idx = torch.arange(chain_windows, device=conditions.device) % n
+            self.xc_chain = conditions.detach().to(dev, torch.float32)[idx].contiguous()
+            self.xT_chain = torch.randn((chain_windows, T, D), generator=gc).to(dev)
+            self.conditions = f"caller ({min(n, chain_windows)} windows)"
+        elif probe is None and chain_windows is not None and chain_windows > B:
+            self.conditions = "self-generated"
             gc = torch.Generator().manual_seed(self.SEED + 2)
             self.xT_chain = torch.randn((chain_windows, T, D), generator=gc).to(dev)
             self.xc_chain = torch.randn((chain_windows, T, D), generator=gc).to(dev)
@@ -91,6 +107,9 @@ class PrecisionProbe:
                 mask = head_condition_mask(gen.shape, device=dev)
                 self.xc_chain = (gen * (1.0 - mask) + mask * self.xc_chain).contiguous()
         self._want_chain = None
+        self._mid_chain = None  # the reference chain's state with t_gain steps to go (chain_gain)
+        self._gain = None
+        self.t_gain = max(1, min(S - 1, int(round(self.GAIN_AT * S)))) if S > 1 else 0
         if S > 2 and probe is None:
             self.cases.append((S // 2, self._renoise(S // 2)))
         self.n_tail = min(tail, S)
@@ -141,10 +160,45 @@ class PrecisionProbe:
         finally:
             eng.close()
 
-    def _full_chain(self, eng):
+    def _full_chain(self, eng, keep_mid=False):
         x = self.xT_chain.clone()
-        eng.sample_loop_(x, self.xc_chain, self.S - 1, self.S, noise_mode=_lib.NOISE_PHILOX, seed=self.SEED + 1)
+        tg = self.t_gain if keep_mid else 0
+        if tg:
+            eng.sample_loop_(x, self.xc_chain, self.S - 1, self.S - tg, noise_mode=_lib.NOISE_PHILOX, seed=self.SEED + 1)
+            self._mid_chain = x.clone()
+            eng.sample_loop_(x, self.xc_chain, tg - 1, tg, noise_mode=_lib.NOISE_PHILOX, seed=self.SEED + 1)  # (the draws are keyed by the timestep: one stream)
+        else:
+            eng.sample_loop_(x, self.xc_chain, self.S - 1, self.S, noise_mode=_lib.NOISE_PHILOX, seed=self.SEED + 1)
         return x
+
+    def _reference_chain(self):
+        if self._want_chain is None:
+            ref = HipEngine(self.cfg, self.sd, self.dev, _lib.PREC_BF16X3, 0)  # (graph replay: a 1000-step chain of ten launches per step)
+            try:
+                self._want_chain = self._full_chain(ref, keep_mid=True)
+                self._gain = None
+                if self._mid_chain is not None:
+                    # the chain's own response to a perturbation, per window, in split-bf16 alone: the same draws from t_gain down with
+                    # GAIN_EPS x N(0, 1) added to x — a chain that contracts it on EVERY window (the reference's initialisation: 0.14-0.20 of it
+                    # survives, max / median 1.4 over 256 windows) cannot accumulate 16-bit fixed-point rounding; one whose response is
+                    # heavy-tailed over windows (50 Adam steps: median 0.08, max 1.5) holds windows that multiply it
+                    g = torch.Generator().manual_seed(self.SEED + 3)
+                    y = self._mid_chain + self.GAIN_EPS * torch.randn(self._mid_chain.shape, generator=g).to(self.dev)
+                    ref.sample_loop_(y, self.xc_chain, self.t_gain - 1, self.t_gain, noise_mode=_lib.NOISE_PHILOX, seed=self.SEED + 1)
+                    self._gain = ((y - self._want_chain).abs().amax((1, 2)) / self.GAIN_EPS).cpu()
+                    self._mid_chain = None
+            finally:
+                ref.close()
+        return self._want_chain
+
+    @torch.no_grad()
+    def chain_gain(self):
+        """(max, median) over the chain batch's windows of |final pose of the perturbed split-bf16 chain - of the unperturbed one|max / GAIN_EPS,
+        the perturbation added with t_gain = GAIN_AT x S steps to go; None when the chain is too short to split."""
+        self._reference_chain()
+        if self._gain is None:
+            return None
+        return float(self._gain.max()), float(self._gain.median())
 
     @torch.no_grad()
     def chain_error(self, sd, prec, row_shift=None, flags=0):
@@ -152,15 +206,10 @@ class PrecisionProbe:
         between (sd, prec) and the split-bf16 engine, on the chain batch.  What `error`'s 50-step tail under-predicts on a trained
         denoiser: round 4 measured 1.5e-4 there and 5.1e-4 here for the same packing (the high-noise half of the chain contributes as
         much as the end).  ~0.3-0.5 s per engine at S = 1000 (graph replay)."""
-        if self._want_chain is None:
-            ref = HipEngine(self.cfg, self.sd, self.dev, _lib.PREC_BF16X3, 0)  # (graph replay: a 1000-step chain of ten launches per step)
-            try:
-                self._want_chain = self._full_chain(ref)
-            finally:
-                ref.close()
+        want = self._reference_chain()
         eng = HipEngine(self.cfg, sd, self.dev, prec, flags, row_shift=row_shift)
         try:
-            d = (self._full_chain(eng) - self._want_chain).abs().amax((1, 2))
+            d = (self._full_chain(eng) - want).abs().amax((1, 2))
             return float(d.max()), [float(v) for v in d]
         finally:
             eng.close()

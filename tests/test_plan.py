@@ -145,11 +145,17 @@ def test_eight_gloo_ranks_even_and_ragged(tmp_path):
 class _ScriptedProbe:
     """Stand-in for precision.PrecisionProbe: errors per (precision, form) come from a table (no GPU)."""
     table = {}
+    gain = (0.2, 0.14)  # (max, median) of chain_gain: the initialisation's figures unless a case sets others
 
-    def __init__(self, model, tail=0, chain_windows=0):
+    def __init__(self, model, tail=0, chain_windows=0, conditions=None):
         self.sd = {"w": torch.zeros(2)}
         self.last_forward_error = 0.0
         self.calls = []
+        self.t_gain = 400
+        self.conditions = "self-generated" if conditions is None else f"caller ({conditions.shape[0]} windows)"
+
+    def chain_gain(self):
+        return self.gain
 
     def calibration(self):
         return {"rows": {}, "n_layers": 0}
@@ -167,8 +173,9 @@ class _ScriptedProbe:
         pass
 
 
-def _scripted(monkeypatch, table):
+def _scripted(monkeypatch, table, gain=(0.2, 0.14)):
     _ScriptedProbe.table = table
+    _ScriptedProbe.gain = gain
     monkeypatch.setattr(plan, "PrecisionProbe", _ScriptedProbe)
 
     def fake_prepare(sd, calib, prec, shift=True, fc24=False, ffn16=False, cache=None, **kw):
@@ -191,7 +198,20 @@ def test_ladder_decisions_with_a_scripted_probe(monkeypatch):
     _scripted(monkeypatch, {(9, "as is"): (7.4e-4, 6e-4, 0), (9, "prepared"): (1.5e-4, 1.24e-4, 9.7e-4)})
     p = plan.run_ladder(m)
     assert p["precision"] == 3 and "amplifies operand rounding 7.8x" in p["warn"] and set(p["probe"]["errors"]) == {
-        "9 as is", "9 prepared", "9 prepared, full chain", "9 prepared, amplification"}
+        "9 as is", "9 prepared", "9 prepared, full chain", "9 prepared, amplification", "chain gain, max", "chain gain, median"}
+    # 2b. (round 6) the pattern of a checkpoint 50 Adam steps from the initialisation: every error figure is the initialisation's — stage 1, whole
+    #     chain, chain / forward 1.1 — but the chain's response to a perturbation is heavy-tailed over windows (max 1.5, median 0.08): split-bf16.
+    #     And a uniform response that is merely large (max 0.8 at a median of 0.6) is refused as well
+    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(1.55, 0.081))
+    p = plan.run_ladder(m, conditions=torch.zeros(256, 30, 198))
+    assert p["precision"] == 3 and "does not contract a perturbation evenly over windows" in p["warn"] and "caller (256 windows)" in p["warn"]
+    assert p["probe"]["errors"]["chain gain, max"] == 1.55 and p["probe"]["conditions"] == "caller (256 windows)"
+    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.8, 0.6))
+    assert plan.run_ladder(m)["precision"] == 3
+    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.24, 0.077))  # (70 steps: x3.1 — safe as measured, refused all the same)
+    assert plan.run_ladder(m)["precision"] == 3
+    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.108, 0.082))  # (10 steps: x1.3)
+    assert plan.run_ladder(m)["precision"] == 9
     # 3. the same forward errors on a chain that does NOT amplify but whose worst window is over the limit: the ladder walks on, and
     #    precision 8 with the FFN on split-bf16 is the first form inside everything
     tab = {(9, "as is"): (7e-4, 6e-4, 0), (9, "prepared"): (4e-4, 3.9e-4, C * 1.1), (9, "prepared + fc24"): (3.9e-4, 3.8e-4, C * 1.05),
@@ -217,6 +237,24 @@ def test_ladder_decisions_with_a_scripted_probe(monkeypatch):
     p = plan.run_ladder(m)
     assert (p["precision"], p["form"]) == (8, "prepared + ffn16") and p["probe"]["errors"]["8 prepared + ffn16, amplification"] == 2e-3 / 1e-4
     assert A == 3.0 and C == 6.0e-4 and plan.CHAIN_WINDOWS == 128  # (the figures DESIGN.md 3c derives)
+    assert (plan.GAIN_LIMIT, plan.GAIN_TAIL_LIMIT) == (0.5, 2.5)
+
+
+def test_an_int8_plan_is_measured_once_more_on_the_callers_conditions():
+    """plan.wants_caller_conditions: an int8 form `auto` accepted on the probe's self-generated conditions is re-measured the first time a chain-level
+    call hands its own x_cond rows over; a verdict measured on a caller's conditions, split-bf16, an explicit precision or a mismatching window
+    length is left alone."""
+    m = CondGaussianDiffusion(**ModelConfig(max_timesteps=31).ctor_kwargs())
+    cond = torch.zeros(40, 30, 198)
+    own = dict(plan.plain_plan(9, "probe"), probe={"conditions": "self-generated"})
+    assert plan.wants_caller_conditions(m, own, cond)
+    assert plan.wants_caller_conditions(m, dict(own, source="cache"), cond) and plan.wants_caller_conditions(m, dict(own, source="group rank 0 (probe)"), cond)
+    assert not plan.wants_caller_conditions(m, dict(own, probe={"conditions": "caller (40 windows)"}), cond)
+    assert not plan.wants_caller_conditions(m, dict(own, precision=3), cond) and not plan.wants_caller_conditions(m, own, None)
+    assert not plan.wants_caller_conditions(m, own, torch.zeros(40, 12, 198))  # (a trailing window of the harness)
+    assert not plan.wants_caller_conditions(m, dict(own, source="no probe"), cond)
+    m.hip_precision = 9
+    assert not plan.wants_caller_conditions(m, own, cond)
 
 
 def test_harness_sizes_its_plan_by_the_global_job(tmp_path, monkeypatch):
@@ -232,7 +270,7 @@ def test_harness_sizes_its_plan_by_the_global_job(tmp_path, monkeypatch):
     class Stop(Exception):
         pass
 
-    def fake_engine(verify=False, masked=False, job=None, group=None):
+    def fake_engine(verify=False, masked=False, job=None, group=None, conditions=None):
         seen["job"] = job
         raise Stop()
     m.hip_engine = fake_engine

@@ -55,12 +55,12 @@ def main():
                     warnings.simplefilter("ignore")
                     res = chain_tail(sd, T, args.batch, args.forms.split(","), cache=False, log=log)
                 a = res["auto"]
-                amp = {k.replace(", amplification", ""): v for k, v in (a["probe"] or {}).items() if k.endswith("amplification")}
+                amp = {k.replace(", amplification", ""): v for k, v in (a["probe"] or {}).items() if k.endswith("amplification") or k.startswith("chain gain")}
                 rows.append((seed, lr, steps, info.get("loss_last"), a["precision"], a["form"], amp, {f: r["vs3"]["max"] for f, r in res.items()}))
     log("== summary: what auto runs, the amplification its probe measured (per candidate that reached stage 2), the worst of 256 windows against split-bf16 per form")
     for seed, lr, steps, loss, prec, form, amp, worst in rows:
         log(f"   seed {seed} lr {lr:g} steps {steps:6d}  l1 {loss if loss is None else format(loss, '.3f')}  auto -> {prec} {form or ''}  amplification "
-            + ", ".join(f"{k}: {v:.1f}x" for k, v in amp.items()) + "  | worst of 256: " + ", ".join(f"{f} {v:.2e}" for f, v in worst.items()))
+            + ", ".join(f"{k}: {v:.2f}x" for k, v in amp.items()) + "  | worst of 256: " + ", ".join(f"{f} {v:.2e}" for f, v in worst.items()))
     if args.out:
         with open(args.out, "w") as f:
             f.write("\n".join(lines) + "\n")

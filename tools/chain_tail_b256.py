@@ -73,7 +73,7 @@ def chain_tail(sd, T, B=256, forms=("auto",), data_seed=31337, seed=11, n_oracle
             warnings.simplefilter("always")
             t0 = time.time()
             m = build(sd, T, form, cache)
-            m.hip_engine(verify=True)
+            m.hip_engine(verify=True, job=(B, T, S), conditions=x_cond)  # (stage 2 of the plan's measurement on this batch's own conditions, like a chain-level call)
             t_pack = time.time() - t0
             t0 = time.time()
             got = philox_chain(m, x_T, x_cond, seed)
