@@ -209,15 +209,15 @@ def trained_like_line(args, cfg, dev, B, T, K, W):
     model.hip_graph = not args.no_graph
     model = model.to(dev)
     import warnings
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        t_pack = time.perf_counter()
-        model.hip_engine(verify=True)
-        t_pack = time.perf_counter() - t_pack
     xs, cm = make_head_windows(B, T, seed=100)
     gen = torch.Generator().manual_seed(1234)
     noise = {"x_T": torch.randn(xs.shape, generator=gen).to(dev), "cond": torch.randn(xs.shape, generator=gen).to(dev)}
     xs, cm = xs.to(dev), cm.to(dev)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        t_pack = time.perf_counter()
+        model.hip_engine(verify=True, job=(B, T, cfg.timesteps), conditions=(xs * (1 - cm) + cm * noise["cond"]).contiguous())
+        t_pack = time.perf_counter() - t_pack
     S = cfg.timesteps
     timed_fn = D.hip_steps_fn(model, S - 1 - W, K, seed=7, verify=False, guard=False)
     D.sample_local(D.hip_steps_fn(model, S - 1, max(W, 1), seed=7), xs, cm, noise)
@@ -354,15 +354,17 @@ def main():
         model.hip_outlier_guard = False
     model.hip_graph = not args.no_graph
     model = model.to(dev)
-    eng = model.hip_engine(verify=True, group=D._group_of(None))  # (N > 1: group rank 0 measures, every rank packs its plan)
-    prec = int(model.hip_precision_used)  # what runs: the probe's pick under "auto"
-
     # the GLOBAL batch (every rank holds it: 24 MB per tensor at B=256); rank r samples the contiguous slice
     # dist.shard_bounds gives it (strong scaling: BASELINE configs[2] is B=256 split over the GPUs of the node)
     xs, cm = make_head_windows(B, T, seed=100)
     gen = torch.Generator().manual_seed(1234)
     noise = {"x_T": torch.randn(xs.shape, generator=gen).to(dev), "cond": torch.randn(xs.shape, generator=gen).to(dev)}
     xs, cm = xs.to(dev), cm.to(dev)
+    # pack: under "auto" the precision is MEASURED here, stage 2 on this job's own conditions (N > 1: group rank 0 measures on its shard's, every rank packs its plan)
+    lo0, hi0 = D.shard_bounds(B, rank, world)
+    xc0 = (xs[lo0:hi0] * (1 - cm[lo0:hi0]) + cm[lo0:hi0] * noise["cond"][lo0:hi0]).contiguous() if hi0 > lo0 else None
+    eng = model.hip_engine(verify=True, group=D._group_of(None), job=(B, T, cfg.timesteps), conditions=xc0)
+    prec = int(model.hip_precision_used)  # what runs: the probe's pick under "auto"
     lo, hi = D.shard_bounds(B, rank, world)
     S = cfg.timesteps
     K, W = args.steps, args.warmup

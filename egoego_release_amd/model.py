@@ -317,7 +317,7 @@ class CondGaussianDiffusion(nn.Module):
         fp = self._weights_fingerprint() if (verify or group is not None) else None
         if conditions is not None and not (conditions.dim() == 3 and conditions.shape[0] >= 1 and int(conditions.shape[1]) == int(self.seq_len)):
             conditions = None  # (a shorter trailing window of the harness, an empty shard: the probe keeps its own)
-        remeasure = (slot.engine is not None and slot.key == key and not slot.force_repack and not slot.caller_checked and job is not None
+        remeasure = (verify and slot.engine is not None and slot.key == key and not slot.force_repack and not slot.caller_checked and job is not None
                      and not plan_mod.is_small_job(self, job) and plan_mod.wants_caller_conditions(self, slot.plan, conditions))
         stale = (slot.engine is None or slot.key != key or (fp is not None and slot.fingerprint != fp) or slot.force_repack or remeasure
                  or (slot.plan is not None and slot.plan["source"] == "small job" and job is not None and not plan_mod.is_small_job(self, job)))
