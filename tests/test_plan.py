@@ -201,15 +201,17 @@ def test_ladder_decisions_with_a_scripted_probe(monkeypatch):
         "9 as is", "9 prepared", "9 prepared, full chain", "9 prepared, amplification", "chain gain, max", "chain gain, median"}
     # 2b. (round 6) the pattern of a checkpoint 50 Adam steps from the initialisation: every error figure is the initialisation's — stage 1, whole
     #     chain, chain / forward 1.1 — but the chain's response to a perturbation is heavy-tailed over windows (max 1.5, median 0.08): split-bf16.
-    #     And a uniform response that is merely large (max 0.8 at a median of 0.6) is refused as well
+    #     And a uniform response that EXPANDS the perturbation (max 1.2 at a median of 0.9) is refused as well
     _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(1.55, 0.081))
     p = plan.run_ladder(m, conditions=torch.zeros(256, 30, 198))
     assert p["precision"] == 3 and "does not contract a perturbation evenly over windows" in p["warn"] and "caller (256 windows)" in p["warn"]
     assert p["probe"]["errors"]["chain gain, max"] == 1.55 and p["probe"]["conditions"] == "caller (256 windows)"
-    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.8, 0.6))
+    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(1.2, 0.9))
     assert plan.run_ladder(m)["precision"] == 3
-    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.24, 0.077))  # (70 steps: x3.1 — safe as measured, refused all the same)
+    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.24, 0.077))  # (x3.1: refused; the 70-step checkpoint's own 128 windows read 0.17 / 0.08 = x2.1 and pass)
     assert plan.run_ladder(m)["precision"] == 3
+    _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.62, 0.37))  # (uniformly less contractive: left to the error limits)
+    assert plan.run_ladder(m)["precision"] == 9
     _scripted(monkeypatch, {(9, "as is"): (1.8e-4, 1.6e-4, 1.8e-4)}, gain=(0.108, 0.082))  # (10 steps: x1.3)
     assert plan.run_ladder(m)["precision"] == 9
     # 3. the same forward errors on a chain that does NOT amplify but whose worst window is over the limit: the ladder walks on, and
@@ -237,7 +239,7 @@ def test_ladder_decisions_with_a_scripted_probe(monkeypatch):
     p = plan.run_ladder(m)
     assert (p["precision"], p["form"]) == (8, "prepared + ffn16") and p["probe"]["errors"]["8 prepared + ffn16, amplification"] == 2e-3 / 1e-4
     assert A == 3.0 and C == 6.0e-4 and plan.CHAIN_WINDOWS == 128  # (the figures DESIGN.md 3c derives)
-    assert (plan.GAIN_LIMIT, plan.GAIN_TAIL_LIMIT) == (0.5, 2.5)
+    assert (plan.GAIN_LIMIT, plan.GAIN_TAIL_LIMIT) == (1.0, 2.5)
 
 
 def test_an_int8_plan_is_measured_once_more_on_the_callers_conditions():
