@@ -96,27 +96,29 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int bh, int qblock,
     u32x4 qb[2][CH][NP];  // Q fragments of the current / next d_k chunk (static ping-pong)
     // K / V^T chunks travel global -> LDS by LDS-DMA (16 B per lane at wave-uniform base + 16*lane: the
     // fragment image itself), one phase ahead of the MFMAs; two slots, so two workgroups fit per CU.
-    // (buffer form, common.h: resources based at this (window, head)'s K / V^T images; stage_off = stage_src's offset inside them)
-    const __amdgpu_buffer_rsrc_t kr = gemm_rsrc(a.k + (((size_t)bh * KT * 16) << 9)), vr = gemm_rsrc(a.v + (((size_t)bh * 8 * 2 * KT) << 9));
+    // (buffer form, common.h: one resource per piece, based at this (window, head)'s image in the piece's PLANE — a plane of 8192 windows is
+    // 2 GiB, beyond a 32-bit offset —; stage_off = stage_src's offset inside that image)
+    auto stage_base = [&](int ph, int j) -> const __bf16* {
+        const int blk = j * 4 + wave;
+        if (ph < NKP) return a.k + (size_t)((blk / CH) / KT) * a.plane + (((size_t)bh * KT * 16) << 9);
+        return a.v + (size_t)((blk / (2 * KT)) / DT) * a.plane + (((size_t)bh * 8 * 2 * KT) << 9);
+    };
     auto stage_off = [&](int ph, int j) -> unsigned {
         const int blk = j * 4 + wave;
         if (ph < NKP) {
-            const int ks = blk % CH, t2 = blk / CH;
-            const int p = t2 / KT, kt = t2 % KT;
-            return (unsigned)(p * a.plane * 2) + (unsigned)((kt * 16 + CH * ph + ks) << 10);
+            const int ks = blk % CH, kt = (blk / CH) % KT;
+            return (unsigned)((kt * 16 + CH * ph + ks) << 10);
         }
-        const int kg = blk % (2 * KT), t2 = blk / (2 * KT);
-        const int p = t2 / DT, dt2 = t2 % DT;
-        return (unsigned)(p * a.plane * 2) + (unsigned)((((DT * (ph - NKP) + dt2) * (2 * KT)) + kg) << 10);
+        const int kg = blk % (2 * KT), dt2 = (blk / (2 * KT)) % DT;
+        return (unsigned)((((DT * (ph - NKP) + dt2) * (2 * KT)) + kg) << 10);
     };
     auto dma_phase = [&](int ph, int slot) {
         char* dst = smem + (size_t)slot * STAGE_BYTES + (size_t)wave * 1024;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0) {
-                if (ph < NKP) gemm_dma_piece(kr, dst + (size_t)j * 4096, stage_off(ph, j), lane);
-                else gemm_dma_piece(vr, dst + (size_t)j * 4096, stage_off(ph, j), lane);
-            } else
+            if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0)
+                gemm_dma_piece(gemm_rsrc(stage_base(ph, j)), dst + (size_t)j * 4096, stage_off(ph, j), lane);
+            else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)stage_src(ph, j),
                                                  (__attribute__((address_space(3))) void*)(dst + (size_t)j * 4096), 16, 0, 0);
         }
@@ -329,26 +331,27 @@ __global__ __launch_bounds__(512, 1) void attn8_kernel(AttnArgs a) {
             return (const u32x4*)(a.v + (size_t)p * a.plane) + (((size_t)bh * 8 + (ph - NKP)) * (2 * KT) + kg) * 64 + lane;
         }
     };
-    const __amdgpu_buffer_rsrc_t kr = gemm_rsrc(a.k + (((size_t)bh * KT * 16) << 9)), vr = gemm_rsrc(a.v + (((size_t)bh * 8 * 2 * KT) << 9));
-    auto stage_off = [&](int ph, int j) -> unsigned {  // stage_src's byte offset inside this (window, head)'s K / V^T image (buffer form, common.h)
+    auto stage_base = [&](int ph, int j) -> const __bf16* {  // (buffer form, common.h) this (window, head)'s image in the piece's plane
+        const int blk = min(j * 8 + wave, NBLK - 1);
+        if (ph < NKP) return a.k + (size_t)((blk / CH) / KT) * a.plane + (((size_t)bh * KT * 16) << 9);
+        return a.v + (size_t)(blk / (2 * KT)) * a.plane + (((size_t)bh * 8 * 2 * KT) << 9);
+    };
+    auto stage_off = [&](int ph, int j) -> unsigned {  // stage_src's byte offset inside that image
         const int blk = min(j * 8 + wave, NBLK - 1);
         if (ph < NKP) {
-            const int ks = blk % CH, t2 = blk / CH;
-            const int p = t2 / KT, kt = t2 % KT;
-            return (unsigned)(p * a.plane * 2) + (unsigned)((kt * 16 + CH * ph + ks) << 10);
+            const int ks = blk % CH, kt = (blk / CH) % KT;
+            return (unsigned)((kt * 16 + CH * ph + ks) << 10);
         }
-        const int kg = blk % (2 * KT), p = blk / (2 * KT);
-        return (unsigned)(p * a.plane * 2) + (unsigned)((((ph - NKP) * (2 * KT)) + kg) << 10);
+        return (unsigned)((((ph - NKP) * (2 * KT)) + blk % (2 * KT)) << 10);
     };
     auto dma_phase = [&](int ph) {
         char* dst = smem + (size_t)(ph % NSLOT) * STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             char* d = dst + (size_t)min(j * 8 + wave, NBLK - 1) * 1024;
-            if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0) {
-                if (ph < NKP) gemm_dma_piece(kr, d, stage_off(ph, j), lane);
-                else gemm_dma_piece(vr, d, stage_off(ph, j), lane);
-            } else
+            if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0)
+                gemm_dma_piece(gemm_rsrc(stage_base(ph, j)), d, stage_off(ph, j), lane);
+            else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)stage_src(ph, j), (__attribute__((address_space(3))) void*)d, 16, 0, 0);
         }
     };

@@ -158,8 +158,8 @@ struct GemmBody {
         const int ns = (g.kcount ? g.kcount : g.K16) / KS;
         const u32x4* gp[NCH];
         int dsto[NCH];
-        unsigned boff[NCH];  // (buffer form) byte offset of chunk j's block inside its operand's resource
-        bool isw[NCH];
+        unsigned boff[NCH];       // (buffer form) byte offset of chunk j's block inside its operand PLANE: wave-uniform, lives in an SGPR
+        const __bf16* bbase[NCH]; // (buffer form) that plane's base (weights) / this token block's first row tile in it (activations): wave-uniform
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int blk = min(j * NW + wave, C::NBLK - 1);
@@ -169,18 +169,17 @@ struct GemmBody {
             if (t2 < WT * NP) {
                 const int p = t2 / WT, i = t2 % WT;
                 base = (const u32x4*)(g.w + (size_t)p * g.w_plane) + ((size_t)(fblk * WT + i) * g.K16 + ks) * 64;
-                boff[j] = (unsigned)(p * g.w_plane * 2) + (unsigned)(((fblk * WT + i) * g.K16 + ks) << 10);
-                isw[j] = true;
+                boff[j] = (unsigned)(((fblk * WT + i) * g.K16 + ks) << 10);
+                bbase[j] = g.w + (size_t)p * g.w_plane;
             } else {
                 const int t3 = t2 - WT * NP;
                 const int p = t3 / AT, i = t3 % AT;
                 base = (const u32x4*)(g.a + (size_t)p * g.a_plane) + ((size_t)(tblk * AT + i) * g.K16 + ks) * 64;
-                boff[j] = (unsigned)(p * g.a_plane * 2) + (unsigned)((i * g.K16 + ks) << 10);
-                isw[j] = false;
+                boff[j] = (unsigned)((i * g.K16 + ks) << 10);
+                bbase[j] = g.a + (size_t)p * g.a_plane + ((size_t)tblk * AT * g.K16 << 9);
             }
             gp[j] = base + lane;
         }
-        const __amdgpu_buffer_rsrc_t wr = gemm_rsrc(g.w), ar = gemm_rsrc(g.a + ((size_t)tblk * AT * g.K16 << 9));
         // (stage 0's requests before stage 1's: the main loop's first counted wait leaves exactly the newest stage in flight)
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -189,8 +188,7 @@ struct GemmBody {
                 for (int j = 0; j < NCH; ++j) {
                     if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0) {
                         char* dst = smem + (size_t)d * C::STAGE_BYTES + dsto[j];
-                        if (isw[j]) gemm_dma_piece(wr, dst, boff[j] + (unsigned)(d * KS * 1024), lane);
-                        else gemm_dma_piece(ar, dst, boff[j] + (unsigned)(d * KS * 1024), lane);
+                        gemm_dma_piece(gemm_rsrc(bbase[j]), dst, boff[j] + (unsigned)(d * KS * 1024), lane);
                     } else
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (size_t)d * KS * 64),
                                                          (__attribute__((address_space(3))) void*)(smem + (size_t)d * C::STAGE_BYTES + dsto[j]), 16, 0, 0);
@@ -214,8 +212,8 @@ struct GemmBody {
         // Per-thread source pointers of this stage's chunks (wave-uniform base + lane).
         const u32x4* gp[NCH];
         int dsto[NCH];  // byte offset of chunk j's block inside a stage
-        unsigned boff[NCH];  // (buffer form) byte offset of chunk j's block inside its operand's resource: wave-uniform, lives in an SGPR
-        bool isw[NCH];
+        unsigned boff[NCH];       // (buffer form) byte offset of chunk j's block inside its operand PLANE: wave-uniform, lives in an SGPR
+        const __bf16* bbase[NCH]; // (buffer form) that plane's base (weights) / this token block's first row tile in it (activations): wave-uniform
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int blk = min(j * NW + wave, C::NBLK - 1);
@@ -225,19 +223,19 @@ struct GemmBody {
             if (t2 < WT * NP) {
                 const int p = t2 / WT, i = t2 % WT;
                 base = (const u32x4*)(g.w + (size_t)p * g.w_plane) + ((size_t)(fblk * WT + i) * g.K16 + ks) * 64;
-                boff[j] = (unsigned)(p * g.w_plane * 2) + (unsigned)(((fblk * WT + i) * g.K16 + ks) << 10);
-                isw[j] = true;
+                boff[j] = (unsigned)(((fblk * WT + i) * g.K16 + ks) << 10);
+                bbase[j] = g.w + (size_t)p * g.w_plane;
             } else {
                 const int t3 = t2 - WT * NP;
                 const int p = t3 / AT, i = t3 % AT;
                 base = (const u32x4*)(g.a + (size_t)p * g.a_plane) + ((size_t)(tblk * AT + i) * g.K16 + ks) * 64;
-                boff[j] = (unsigned)(p * g.a_plane * 2) + (unsigned)((i * g.K16 + ks) << 10);
-                isw[j] = false;
+                boff[j] = (unsigned)((i * g.K16 + ks) << 10);
+                bbase[j] = g.a + (size_t)p * g.a_plane + ((size_t)tblk * AT * g.K16 << 9);
             }
             gp[j] = base + lane;
         }
-        // (buffer form) the weights from their base, the activations from this token block's first row tile: offsets stay far below 2^31
-        const __amdgpu_buffer_rsrc_t wr = gemm_rsrc(g.w), ar = gemm_rsrc(g.a + ((size_t)tblk * AT * g.K16 << 9));
+        // (buffer form: one resource per chunk, built from its plane's base at issue time — a few SALU operations — so that the 32-bit offsets
+        // stay inside ONE plane of ONE token block / the weight matrix whatever the batch: a plane of 8192 windows' attention output is 2 GiB)
 
         if (ZERO) {
 #pragma unroll
@@ -285,8 +283,7 @@ struct GemmBody {
         auto issue_one = [&](int stage, int slot, int j) {
             char* dst = smem + (size_t)slot * C::STAGE_BYTES;
             if constexpr (EGOEGO_GEMM_BUFFER_DMA != 0) {
-                if (isw[j]) gemm_dma_piece(wr, dst + dsto[j], boff[j] + (unsigned)(stage * KS * 1024), lane);
-                else gemm_dma_piece(ar, dst + dsto[j], boff[j] + (unsigned)(stage * KS * 1024), lane);
+                gemm_dma_piece(gemm_rsrc(bbase[j]), dst + dsto[j], boff[j] + (unsigned)(stage * KS * 1024), lane);
             } else
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(gp[j] + (size_t)stage * KS * 64),

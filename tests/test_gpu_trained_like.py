@@ -371,7 +371,9 @@ def test_whole_chain_at_the_metrics_size_b256(trained):
     print(f"trained-like: auto runs {r['precision']} ({r['warnings'][:1]}); amplification {amp}; largest move of a split-bf16 chain under a 1e-6 "
           f"perturbation of x_T: {float(sens.max()):.1e}")
     assert r["precision"] == _lib.PREC_BF16X3 and amp and max(amp.values()) > plan.AMPLIFICATION_LIMIT, r["probe"]
-    assert any("amplifies operand rounding" in w for w in r["warnings"]), r["warnings"]
+    # (round 6: the chain's response to a perturbation is checked first — max 1.5-3.5 at a median of 0.6-0.7 on this checkpoint — so the warning names that figure)
+    assert any("amplifies operand rounding" in w or "does not contract a perturbation" in w for w in r["warnings"]), r["warnings"]
+    assert r["probe"]["chain gain, max"] > plan.GAIN_LIMIT
     assert float(sens.max()) <= 1e-4  # ... and it is not chaos: the split-bf16 chain itself is reproducible on every window
     # the best int8 form on the same batch (what an explicit hip_precision would run): typical windows sit inside the bar, which is all a
     # sample can say about a chain that amplifies (2 of 6 such checkpoints held a window 1e-2 away)
