@@ -31,8 +31,11 @@ def main():
     ap.add_argument("--window", type=int, default=120)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--forms", default="auto,9,8pn")
+    ap.add_argument("--probe-windows", type=int, default=0, help="windows of the plan's whole-chain stage (default: plan.CHAIN_WINDOWS)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
+    if args.probe_windows:
+        plan.CHAIN_WINDOWS = args.probe_windows
     T = args.window
     lines = []
 
