@@ -37,6 +37,7 @@ PROBE_TAIL = 50          # ancestral steps of stage 1's end-of-chain run
 CHAIN_WINDOWS = 128      # stage 2: windows of the whole-chain probe, conditions shaped like the reference's use (precision.PrecisionProbe).  Round 4
                          # used 4 windows, round 5 first 32: two draws of 32 windows read the SAME packing 4.95e-4 and 7.06e-4, and one draw
                          # accepted a checkpoint whose real batch holds a window 9.9e-3 away (profiles/r05_chain_tail_probe128_*.txt)
+CHAIN_WINDOWS_CALLER = 256  # ... and when the chain-level call hands its own conditions over (round 6), ALL of its windows up to this many
 CHAIN_LIMIT = 6.0e-4     # stage 2: the worst of CHAIN_WINDOWS whole chains against split-bf16.  DERIVED (round 5, profiles/r05_chain_tail_*.txt): the bar is
                          # 1e-3 against the fp32 reference; split-bf16 itself ends whole chains <= 1.24e-4 from the fp32 oracle (16 windows), which
                          # leaves 8.5e-4 against split-bf16 for the worst window of a B = 256 batch; that worst window sat at <= 1.40x the 128-window
@@ -108,7 +109,7 @@ def run_ladder(model, conditions=None):
     want = model.hip_precision
     explicit = want != "auto" or model.hip_plan_override is not None
     full_chain = model.hip_probe_full_chain and (want == "auto" or model.hip_plan_override is not None)
-    probe = PrecisionProbe(model, tail=PROBE_TAIL, chain_windows=CHAIN_WINDOWS, conditions=conditions)
+    probe = PrecisionProbe(model, tail=PROBE_TAIL, chain_windows=CHAIN_WINDOWS, conditions=conditions, caller_windows_max=CHAIN_WINDOWS_CALLER)
     errors, calib, pick, best, rounded, amplifies, unstable = {}, None, None, None, {}, None, None
     try:
         sd = probe.sd
@@ -214,7 +215,7 @@ def cache_key(model, fingerprint):
     what = [_lib.ABI_VERSION, _lib_hash(), [repr(v) for v in fingerprint], sorted(_engine_cfg(model).items()), str(model.hip_precision),
             model.hip_int8_prep, bool(model.hip_fc24), bool(model.hip_ffn16), bool(model.hip_probe_full_chain),
             list(model.hip_plan_override) if model.hip_plan_override is not None else None,
-            PROBE_LIMIT, PROBE_TAIL, CHAIN_WINDOWS, CHAIN_LIMIT, AMPLIFICATION_LIMIT, GAIN_LIMIT, GAIN_TAIL_LIMIT,
+            PROBE_LIMIT, PROBE_TAIL, CHAIN_WINDOWS, CHAIN_WINDOWS_CALLER, CHAIN_LIMIT, AMPLIFICATION_LIMIT, GAIN_LIMIT, GAIN_TAIL_LIMIT,
             torch.cuda.get_device_name(model.betas.device) if model.betas.device.type == "cuda" else str(model.betas.device)]
     return hashlib.sha256(json.dumps(what, sort_keys=True, default=str).encode()).hexdigest()[:32]
 

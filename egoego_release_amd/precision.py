@@ -49,7 +49,7 @@ class PrecisionProbe:
     GAIN_EPS = 1e-4        # size of the deliberate perturbation of `chain_gain` (per element, N(0, 1) x this)
     GAIN_AT = 0.4          # ... added to x when this fraction of the chain is still to run (the tails showed most there: r06_contraction_vs_training.txt)
 
-    def __init__(self, model, probe=None, tail=30, chain_windows=None, conditions=None):
+    def __init__(self, model, probe=None, tail=30, chain_windows=None, conditions=None, caller_windows_max=None):
         self.model = model
         self.dev = model.betas.device
         self.cfg = _engine_cfg(model)
@@ -84,8 +84,12 @@ class PrecisionProbe:
             # `chain_windows` windows.  What a chain does to a perturbation depends on what it is conditioned on: a barely trained checkpoint's
             # self-generated conditions (below) excite none of the window-specific instabilities that real head trajectories do — the probe
             # read 4.8e-4 where the caller's 256 windows held 4.5e-3 (profiles/r06_amplification_vs_training.txt)
+            # ALL of the caller's windows, up to `caller_windows_max` (and at least `chain_windows`, cycling): the unstable windows of a barely
+            # trained checkpoint are condition-driven and rare — at T = 196, 50 Adam steps, the one window that ended 2.2e-2 away was not among
+            # the batch's first 128 (profiles/r06_gate_on_caller_conditions.txt)
             gc = torch.Generator().manual_seed(self.SEED + 2)
             n = int(conditions.shape[0])
+            chain_windows = max(chain_windows, min(n, caller_windows_max or chain_windows))
             idx = torch.arange(chain_windows, device=conditions.device) % n
             self.xc_chain = conditions.detach().to(dev, torch.float32)[idx].contiguous()
             self.xT_chain = torch.randn((chain_windows, T, D), generator=gc).to(dev)

@@ -147,7 +147,7 @@ class _ScriptedProbe:
     table = {}
     gain = (0.2, 0.14)  # (max, median) of chain_gain: the initialisation's figures unless a case sets others
 
-    def __init__(self, model, tail=0, chain_windows=0, conditions=None):
+    def __init__(self, model, tail=0, chain_windows=0, conditions=None, caller_windows_max=None):
         self.sd = {"w": torch.zeros(2)}
         self.last_forward_error = 0.0
         self.calls = []
