@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--window", type=int, default=120)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--forms", default="auto,9,8pn")
+    ap.add_argument("--data-seeds", default="31337", help="seeds of the caller's batch (synthetic.make_motion_windows + x_T): every (checkpoint, batch) pair is measured afresh, "
+                                                          "so 'auto' is what that batch as a FIRST call would get and '9' what a verdict reached elsewhere would do to it")
     ap.add_argument("--probe-windows", type=int, default=0, help="windows of the plan's whole-chain stage (default: plan.CHAIN_WINDOWS)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -54,12 +56,16 @@ def main():
                     sd, info = train_like(steps, seed, "cuda", T, lr=lr)
                     sd = {k: v for k, v in sd.items() if k.startswith("denoise_fn.")}
                 log(f"== seed {seed}, lr {lr:g}, {steps} Adam steps: l1 {info.get('loss_first')} -> {info.get('loss_last')}")
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    res = chain_tail(sd, T, args.batch, args.forms.split(","), cache=False, log=log)
-                a = res["auto"]
-                amp = {k.replace(", amplification", ""): v for k, v in (a["probe"] or {}).items() if k.endswith("amplification") or k.startswith("chain gain")}
-                rows.append((seed, lr, steps, info.get("loss_last"), a["precision"], a["form"], amp, {f: r["vs3"]["max"] for f, r in res.items()}))
+                for ds in [int(v) for v in args.data_seeds.split(",")]:
+                    if "," in args.data_seeds:
+                        log(f"-- batch (data seed) {ds}")
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        res = chain_tail(sd, T, args.batch, args.forms.split(","), data_seed=ds, cache=False, log=log)
+                    a = res["auto"]
+                    amp = {k.replace(", amplification", ""): v for k, v in (a["probe"] or {}).items() if k.endswith("amplification") or k.startswith("chain gain")}
+                    rows.append((seed if "," not in args.data_seeds else f"{seed}/batch {ds}", lr, steps, info.get("loss_last"), a["precision"], a["form"], amp,
+                                 {f: r["vs3"]["max"] for f, r in res.items()}))
     log("== summary: what auto runs, the amplification its probe measured (per candidate that reached stage 2), the worst of 256 windows against split-bf16 per form")
     for seed, lr, steps, loss, prec, form, amp, worst in rows:
         log(f"   seed {seed} lr {lr:g} steps {steps:6d}  l1 {loss if loss is None else format(loss, '.3f')}  auto -> {prec} {form or ''}  amplification "
