@@ -488,12 +488,12 @@ static int launch_attn(const AttnArgs& a, int KT, int BH, hipStream_t s) {
 }
 
 // Fused small-batch tail (tail_fused.h): 64-token workgroups when they fill the CUs exactly once, 32-token ones below.
-// EGOEGO_TAIL8_BF16=0 (variant builds): the split-bf16 tail of small grids on four 512-register waves, round 4's form
+// -DTAIL8_BF16=0 (variant builds): the split-bf16 tail of small grids on four 512-register waves, round 4's form
 #ifndef TAIL8_BF16
 #define TAIL8_BF16 1
 #endif
-#ifndef TAIL8_MAX_BLOCKS
-#define TAIL8_MAX_BLOCKS 256
+#ifndef TAIL8_BF16_MAX_BLOCKS
+#define TAIL8_BF16_MAX_BLOCKS 160  // 32-token blocks up to which the split-bf16 tail runs as eight-wave workgroups (well under one per CU)
 #endif
 template <bool FFN8>
 static int launch_tail_f(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_t s) {
@@ -507,7 +507,7 @@ static int launch_tail_f(egoego_ctx* c, const TailArgs& ta, int rows, hipStream_
     if (rows / 64 >= 256) {
         c->last_kernel[EGOEGO_K_FC_LN] = FFN8 ? "tail_kernel<2,true,false>" : "tail_kernel<2,false,false>";
         tail_kernel<2, FFN8, false><<<dim3(rows / 64), dim3(256), tail_smem_bytes(2), s>>>(ta);
-    } else if (!FFN8 && TAIL8_BF16 && rows / 32 <= 160) {
+    } else if (!FFN8 && TAIL8_BF16 && rows / 32 <= TAIL8_BF16_MAX_BLOCKS) {
         // well under one workgroup per CU: the eight-wave build (two 256-register waves per SIMD, 64 features each), like the all-int8
         // tail's — a workgroup is a serial chain there, and a SIMD's second wave issues its weight loads and MFMAs in the first one's waits
         // (round 5, ms per step in split-bf16 at B = 1 / 8 / 32: 0.408 / 0.413 / 0.522 against 0.429 / 0.431 / 0.542 on four waves; a tie at 64 windows)

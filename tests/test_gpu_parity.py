@@ -547,7 +547,7 @@ def test_degenerate_inputs_give_finite_results(prec):
 
 def test_outlier_heavy_layernorm_gains_step_the_default_precision_down():
     """One scale per row is 16-bit fixed point: LayerNorm gains far above the rest cost the other features their bits
-    (DESIGN.md 3c).  `hip_precision = "auto"` (the default) MEASURES each checkpoint when it is packed (model._resolve_precision:
+    (DESIGN.md 3c).  `hip_precision = "auto"` (the default) MEASURES each checkpoint when it is packed (plan.resolve / plan.run_ladder:
     int8 slices against split-bf16 on a probe batch): the reference's initialisation runs precision 9 with no warning; the SAME
     six features amplified 25x in every LayerNorm (the worst case found, tools/gain_sweep.py) — and already 3x — step down to
     split-bf16, with a warning, and the stepped-down result is inside the bar; 2x runs precision 8 as is, silently, inside the bar

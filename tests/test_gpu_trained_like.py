@@ -1,4 +1,4 @@
-"""Parity on weights that are NOT the initialisation, and the two precision guards (model.py `_resolve_precision`, `_outlier_guard`).
+"""Parity on weights that are NOT the initialisation, and the two precision guards (plan.py `resolve`, model.py `_outlier_guard`).
 
 The reference's pretrained stage-2 checkpoint is a download this build cannot make (/root/reference/README.md:51-55), so a
 trained-LIKE state dict is made here, on the GPU box, from repo code only: `tools/make_trained_like_checkpoint.train_like`
