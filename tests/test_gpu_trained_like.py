@@ -439,3 +439,33 @@ def test_whatever_auto_accepts_holds_on_the_callers_own_batch(adam_steps, window
     assert r["precision"] == _lib.PREC_BF16X3, "measured in round 6: every int8 form leaves the bar on single windows of these checkpoints"
     assert gains and (gains["chain gain, max"] > plan.GAIN_LIMIT or gains["chain gain, max"] > plan.GAIN_TAIL_LIMIT * gains["chain gain, median"]
                       or any(v > plan.AMPLIFICATION_LIMIT for k, v in r["probe"].items() if k.endswith("amplification")))
+
+
+def test_an_int8_verdict_is_measured_once_more_on_the_first_real_batch(tmp_path, monkeypatch):
+    """plan.wants_caller_conditions end to end: `model.hip_engine()` alone measures on the probe's self-generated conditions; the first chain-level
+    call that is not a small job hands its own x_cond rows over and stage 2 runs again on them — once: the second call re-measures nothing —, the
+    verdict written to the cache is the caller-conditioned one, and a fresh module that loads it does not measure at all."""
+    monkeypatch.setenv("EGOEGO_HIP_CACHE", str(tmp_path / "cache"))
+    cfg = ModelConfig(max_timesteps=T + 1)
+    sd = make_weights(cfg, 11)
+    xs, cm = make_head_windows(16, T, seed=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m = _build(sd)
+        m.sampling_rng = "philox"
+        m.hip_engine()
+        assert m.hip_precision_used == _lib.PREC_I8X3_FC and m.hip_precision_probe["conditions"] == "self-generated" and not m._slot.caller_checked
+        torch.manual_seed(1)
+        a = m.sample(xs.cuda(), cm.cuda())  # 16 windows x 1000 steps: not a small job
+        pr = m.hip_precision_probe
+        assert m.hip_precision_used == _lib.PREC_I8X3_FC and pr["conditions"] == "caller (16 windows)" and pr["source"] == "probe" and m._slot.caller_checked
+        assert pr["errors"]["chain gain, max"] <= 1.0 and pr["errors"]["chain gain, max"] <= 2.5 * pr["errors"]["chain gain, median"]
+        eng = m._slot.engine
+        torch.manual_seed(1)
+        b = m.sample(xs.cuda(), cm.cuda())
+        assert m._slot.engine is eng and torch.equal(a, b)  # nothing re-packed, same bits
+        m2 = _build(sd)
+        m2.sampling_rng = "philox"
+        torch.manual_seed(1)
+        c = m2.sample(xs.cuda(), cm.cuda())
+        assert m2.hip_precision_probe["source"] == "cache" and m2.hip_precision_probe["conditions"] == "caller (16 windows)" and torch.equal(a, c)
