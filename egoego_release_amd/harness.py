@@ -40,6 +40,15 @@ def prep_head_condition_mask(data, joint_idx=HEAD_IDX):
     return mask
 
 
+def prep_padding_mask(val_data, seq_len, window):
+    """Trainer.prep_padding_mask (trainer_amass_cond_motion_diffusion.py:223-231): [B, 1, window + 1] bool, True on the time token and the
+    first seq_len[b] frames of window b (what `p_sample_loop(..., padding_mask=)` / `denoise_fn(..., padding_mask=)` take; `sample()` itself
+    drops its padding_mask like the reference's, M:528-532)."""
+    actual = seq_len.to(torch.long) + 1  # + 1: the time token
+    keep = torch.arange(window + 1)[None, :].expand(val_data.shape[0], window + 1) < actual.cpu()[:, None]
+    return keep[:, None, :].to(val_data.device)
+
+
 class SkeletonStats:
     """The three `ds` methods the harness needs, for users without the reference's AMASSDataset
     (which requires human_body_prior + licensed SMPL-H): min/max joint normalisation and quaternion FK

@@ -70,6 +70,17 @@ def test_condition_mask_and_stats_roundtrip():
     assert np.abs(gj.numpy() - gj2).max() < 1e-5 and np.abs(gq.numpy() - gq2).max() < 1e-5
 
 
+def test_prep_padding_mask_matches_the_trainers_formula():
+    """trainer:223-231, restated inline: arange(window + 1) < (seq_len + 1), one row per window, a singleton axis in the middle."""
+    window = 120
+    seq_len = torch.tensor([120, 37, 1, 90])
+    data = torch.zeros(4, window, 198)
+    m = harness.prep_padding_mask(data, seq_len, window)
+    assert m.shape == (4, 1, window + 1) and m.dtype == torch.bool
+    want = torch.arange(window + 1).expand(4, window + 1) < (seq_len + 1)[:, None].repeat(1, window + 1)
+    assert torch.equal(m[:, 0], want) and m[1, 0].sum() == 38 and bool(m[0].all())
+
+
 def test_convert_model_res_to_data_cpu_vs_oracle():
     ds, dso = _skeleton(1)
     g = torch.Generator().manual_seed(3)
